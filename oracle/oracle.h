@@ -1,0 +1,103 @@
+/*
+ * oracle.h -- CPU restatement of the fenicsx-fus spectral-element hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it,
+ * and there only as the checker / reported CPU baseline.  The product path
+ * (fenicsx-fus_amd/csrc, libfusmi.so) never links or calls it.
+ *
+ * Parity status: the contraction/transposition primitives are PINNED against
+ * the reference's own dependency-free header compiled in the build container
+ * (oracle/_ref, recipe in oracle/Makefile) and against the reference's iota
+ * known-answer demo (cpp/mwe/sum_factorisation/main.cpp:42-55).  The reference
+ * holds NO stored golden vectors for the operator / RK4 level (its tests
+ * compare against DOLFINx/FFCx at run time, which cannot run here), so at that
+ * level the restatement is pinned only by analytic known-answer tests and an
+ * independent dense-table evaluation (tests/test_oracle_*.py): operator-level
+ * parity against stored reference values is UNPINNED.
+ *
+ * All citations are relative to /root/reference.
+ * Every function exists as <name>_f64 (double) and <name>_f32 (float), the two
+ * scalar types the reference instantiates (`using T = double|float`).
+ */
+#ifndef FUS_ORACLE_H
+#define FUS_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- 1-D tables (type independent, double) --------------------------------
+ * Basix is third-party and absent from the reference tree; these
+ * restate its published definitions: GLL points = roots of (1-x^2) P'_{N-1},
+ * mapped to [0,1]; gll_warped Lagrange nodes coincide with them.           */
+/* N GLL points/weights on [0,1], monotone increasing; weights sum to 1. */
+void orc_gll(int N, double* pts, double* wts);
+/* GLL weight on [0,1] for each given node (any order). */
+void orc_gll_weights_at(int N, const double* nodes, double* wts);
+/* D[q*N+i] = phi_i'(nodes[q]) for the Lagrange basis on `nodes` (any order).
+ * Replaces tabulate_1d (cpp/fenicsx-sf/common/precompute.hpp:217-234) and the
+ * derivative block copied at spectral_op.hpp:168-170.                      */
+void orc_dphi(int N, const double* nodes, double* D);
+
+#define ORC_DECL(SUF, REAL)                                                                        \
+  /* cpp/fenicsx-sf/common/sum_factorisation.hpp:43-49 */                                          \
+  void orc_transpose3_##SUF(int Na, int Nb, int Nc, int offa, int offb, int offc, const REAL* A,   \
+                            REAL* B);                                                              \
+  /* cpp/fenicsx-sf/common/sum_factorisation.hpp:70-86 (C accumulates) */                          \
+  void orc_contract_##SUF(int Nk, int Na, int Nb, int Nc, int transpose, const REAL* A,            \
+                          const REAL* B, REAL* C);                                                 \
+  /* cpp/fenicsx-sf-naive/common/sum_factorisation.hpp:10-18 */                                    \
+  void orc_transpose2_##SUF(int Na, int Nb, int offa, int offb, const REAL* A, REAL* B);           \
+  /* cpp/fenicsx-sf-naive/common/sum_factorisation.hpp:27-37 (C accumulates) */                    \
+  void orc_contract2_##SUF(int Na, int Nb, int Nk, const REAL* A, const REAL* B, REAL* C);         \
+  /* precompute.hpp:33-94 and :101-213 for 1st-order (multilinear) geometry.                       \
+   * tdim 2|3; xg[nnodes*3]; xdofmap[ncells*2^tdim], tensor vertex order                           \
+   * v = vx + 2 vy + 4 vz; pts/wts = 1-D nodes on [0,1] (any order).                               \
+   * G[ncells*N^tdim*(3|6)] (xx,xy,xz,yy,yz,zz | xx,xy,yy), detJ[ncells*N^tdim];                   \
+   * either output may be NULL. Point index = q0*N^2+q1*N+q2 (x slowest). */                       \
+  void orc_geometry_##SUF(int tdim, int64_t ncells, const REAL* xg, const int32_t* xdofmap, int N, \
+                          const double* pts, const double* wts, REAL* G, REAL* detJ);              \
+  /* spectral_op.hpp:69-86 (+ mass::transform :19-26);  y += M(coeffs) x  (2-D: naive :61-83) */   \
+  void orc_mass_##SUF(int tdim, int64_t ncells, int N, const int32_t* tensor_dofmap,               \
+                      const REAL* detJ, const REAL* coeffs, const REAL* x, REAL* y);               \
+  /* spectral_op.hpp:173-243 (+ stiffness::transform :113-130); y += K(coeffs) x */                \
+  void orc_stiffness3d_##SUF(int64_t ncells, int N, const int32_t* tensor_dofmap, const REAL* G,   \
+                             const REAL* dphi, const REAL* coeffs, const REAL* x, REAL* y);        \
+  /* cpp/fenicsx-sf-naive/common/spectral_op.hpp:273-323 (+ transform :195-207) */                 \
+  void orc_stiffness2d_##SUF(int64_t ncells, int N, const int32_t* tensor_dofmap, const REAL* G,   \
+                             const REAL* dphi, const REAL* coeffs, const REAL* x, REAL* y);        \
+  /* Independent O(N^6) dense-table evaluation of the same bilinear form, the                      \
+   * formulation of cpp/fenicsx-pc/common/precompute_op.hpp:264-290,436-458. */                    \
+  void orc_stiffness3d_dense_##SUF(int64_t ncells, int N, const int32_t* tensor_dofmap,            \
+                                   const REAL* G, const REAL* dphi, const REAL* coeffs,            \
+                                   const REAL* x, REAL* y);                                        \
+  /* Diagonal boundary weights: for each facet f (cell, local facet 0..2*tdim-1,                   \
+   * DOLFINx numbering: hex 0:z=0 1:y=0 2:x=0 3:x=1 4:y=1 5:z=1; quad 0:y=0 1:x=0                  \
+   * 2:x=1 3:y=1), out[dof] += cellcoef[cell] * |J_facet| w_a w_b at the facet's                   \
+   * GLL nodes.  Restates the GLL-collocated facet integrals of                                    \
+   * cpp/fenicsx-sf-naive/benchmarks/PH1/SC1-BM1/forms.py:36-39. */                   \
+  void orc_facet_diag_##SUF(int tdim, int64_t nfacets, const int32_t* facet_cell,                  \
+                            const int32_t* facet_local, const REAL* cellcoef, const REAL* xg,      \
+                            const int32_t* xdofmap, int N, const double* pts, const double* wts,   \
+                            const int32_t* tensor_dofmap, REAL* out);                              \
+  /* Linear.hpp:161-314: init + rk4 with the reference's 9-pass stage structure.                   \
+   * m = lumped mass (Linear.hpp:127-134), src/absb = diagonal facet weights                       \
+   * (tag 1: 1/rho, tag 2: 1/(rho c)).  u,v in/out (u_n, v_n).  Returns #steps.                    \
+   * nthreads<=1: scalar; >1: OpenMP over the vector passes and a coloured                         \
+   * element loop is NOT used -- the operator stays the serial cell loop. */                       \
+  int64_t orc_linear_rk4_##SUF(int tdim, int64_t ncells, int64_t ndofs, int N,                     \
+                               const int32_t* tensor_dofmap, const REAL* G, const REAL* dphi,      \
+                               const REAL* coeff, const REAL* m, const REAL* src,                  \
+                               const REAL* absb, double freq, double p0, double s0, double t0,     \
+                               double tf, double dt, REAL* u, REAL* v);
+
+ORC_DECL(f64, double)
+ORC_DECL(f32, float)
+
+#ifdef __cplusplus
+}
+#endif
+#endif

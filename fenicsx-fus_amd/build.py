@@ -1,0 +1,30 @@
+"""Builds libfusmi.so (HIP kernels + C ABI) in-tree for gfx950 with hipcc.
+
+    python fenicsx-fus_amd/build.py [--force]
+
+The .so lands in fenicsx-fus_amd/fenicsxfus_amd/ so it travels with the source snapshot."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = [os.path.join(HERE, "csrc", f) for f in ("fusmi.hip", "layout.cpp")]
+DEPS = SRC + [os.path.join(HERE, "csrc", f) for f in ("kernels.hpp", "layout.hpp", "tables.hpp", "geom.hpp")] + [
+    os.path.join(HERE, "..", "include", "fusmi.h")]
+OUT = os.path.join(HERE, "fenicsxfus_amd", "libfusmi.so")
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", *SRC,
+           "-o", OUT, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

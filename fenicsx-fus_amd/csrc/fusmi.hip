@@ -1,0 +1,1191 @@
+// fusmi.hip -- C ABI of libfusmi (include/fusmi.h) and host orchestration: handles, dtype/degree
+// dispatch, kernel launches, RK4 loop, halo exchange over RCCL.
+//
+// Reference counterparts: StiffnessSpectral3D / MassSpectral3D (spectral_op.hpp:29-107, 132-284),
+// LinearSpectral3D (Linear.hpp:52-347).  There is no CPU fallback in this file: every compute
+// entry point needs the HIP device and fails with FUS_ERR_HIP without one.
+#include "../../include/fusmi.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "layout.hpp"
+#include "tables.hpp"
+
+using namespace fus;
+
+// -------------------------------------------------------------------------------------------------
+// errors
+// -------------------------------------------------------------------------------------------------
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg)
+{
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(expr)                                                                               \
+  do                                                                                               \
+  {                                                                                                \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(FUS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                 \
+  } while (0)
+#define NCCLCHK(expr)                                                                              \
+  do                                                                                               \
+  {                                                                                                \
+    ncclResult_t r_ = (expr);                                                                      \
+    if (r_ != ncclSuccess)                                                                         \
+      return fail(FUS_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));               \
+  } while (0)
+#define FUSCHK(expr)                                                                               \
+  do                                                                                               \
+  {                                                                                                \
+    int r_ = (expr);                                                                               \
+    if (r_ != FUS_OK)                                                                              \
+      return r_;                                                                                   \
+  } while (0)
+
+// -------------------------------------------------------------------------------------------------
+// handles
+// -------------------------------------------------------------------------------------------------
+struct Prof
+{
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  double done_ms = 0;
+  int64_t done_count = 0;
+};
+
+struct fus_ctx
+{
+  int device = 0;
+  hipStream_t stream = nullptr;
+  int block_elems = 64, waves = 4;
+  bool prof = false;
+  std::map<std::string, Prof> profs;
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1;
+};
+
+struct Neigh
+{
+  int rank;
+  int64_t count;
+  int32_t* d_idx = nullptr;  // internal dof indices
+  void* d_send = nullptr;
+  void* d_recv = nullptr;
+};
+
+struct fus_op
+{
+  fus_ctx* ctx;
+  int P, N, Nd, dtype;
+  size_t ts;  // sizeof(T)
+  int64_t ncells, ndofs, nnodes;
+  Layout L;
+  std::vector<double> nodes, wts, D;
+  std::vector<char> h_geom_x;        // caller geometry (host copy, T)
+  std::vector<int32_t> h_geom_dm;    // [ncells*8]
+  std::vector<int32_t> h_dofmap;     // caller tensor dofmap
+  // device
+  BlockArgs A{};
+  std::vector<void*> allocs;
+  int32_t *d_cell_perm = nullptr, *d_dof_perm = nullptr;
+  int64_t *d_sh_ptr = nullptr, *d_sh_pairs = nullptr;
+  void *d_G = nullptr, *d_detJ = nullptr, *d_Dg = nullptr, *d_partial = nullptr;
+  void *d_tmp_x = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr, *d_tmp_coef = nullptr;
+  size_t lds_bytes = 0;
+  // neighbours (multi-GPU)
+  std::vector<Neigh> neigh;
+  int32_t* d_uidx = nullptr;  // unique interface dofs (internal)
+  int64_t n_uidx = 0;
+  void* d_own = nullptr;
+};
+
+struct fus_model
+{
+  fus_ctx* ctx;
+  fus_op* op;
+  int kind;
+  double freq, amp, speed;
+  void *u0 = nullptr, *v0 = nullptr, *u_ = nullptr, *v_ = nullptr, *un = nullptr, *vn = nullptr,
+       *b = nullptr, *minv = nullptr, *m = nullptr, *coef = nullptr;
+  int64_t nb = 0;  // boundary dofs
+  int32_t* d_bidx = nullptr;
+  void *d_bsrc = nullptr, *d_babs = nullptr;
+  std::vector<void*> allocs;
+  bool initialised = false;
+};
+
+// -------------------------------------------------------------------------------------------------
+// small helpers
+// -------------------------------------------------------------------------------------------------
+template <typename U>
+static int dalloc(std::vector<void*>& pool, U** p, size_t n)
+{
+  void* q = nullptr;
+  HIPCHK(hipMalloc(&q, std::max<size_t>(n, 1) * sizeof(U)));
+  pool.push_back(q);
+  *p = static_cast<U*>(q);
+  return FUS_OK;
+}
+static int dalloc_bytes(std::vector<void*>& pool, void** p, size_t bytes, bool zero, hipStream_t st)
+{
+  void* q = nullptr;
+  HIPCHK(hipMalloc(&q, std::max<size_t>(bytes, 16)));
+  pool.push_back(q);
+  if (zero)
+    HIPCHK(hipMemsetAsync(q, 0, std::max<size_t>(bytes, 16), st));
+  *p = q;
+  return FUS_OK;
+}
+template <typename U>
+static int upload(std::vector<void*>& pool, U** p, const std::vector<U>& v, hipStream_t st)
+{
+  FUSCHK(dalloc(pool, p, v.size()));
+  if (!v.empty())
+    HIPCHK(hipMemcpyAsync(*p, v.data(), v.size() * sizeof(U), hipMemcpyHostToDevice, st));
+  return FUS_OK;
+}
+static inline unsigned nblk(int64_t n, int bs = 256) { return (unsigned)((n + bs - 1) / bs); }
+
+struct ProfScope
+{
+  fus_ctx* c;
+  Prof* p = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ProfScope(fus_ctx* c_, const char* name) : c(c_)
+  {
+    if (c->prof)
+    {
+      p = &c->profs[name];
+      (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+      (void)hipEventRecord(e0, c->stream);
+    }
+  }
+  ~ProfScope()
+  {
+    if (p)
+    {
+      (void)hipEventRecord(e1, c->stream);
+      p->ev.emplace_back(e0, e1);
+    }
+  }
+};
+
+// -------------------------------------------------------------------------------------------------
+// typed implementation
+// -------------------------------------------------------------------------------------------------
+template <typename T, int P, int OP>
+static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec)
+{
+  constexpr int N = P + 1;
+  DTab<T, N> Dk;
+  for (int i = 0; i < N * N; ++i)
+    Dk.d[i] = (T)op->D[i];
+  static bool attr_set = false;  // per instantiation
+  if (!attr_set)
+  {
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_block_op<T, P, OP>), dim3(op->L.nblocks), dim3(64 * op->L.waves),
+                     op->lds_bytes, op->ctx->stream, op->A, Dk, static_cast<const T*>(op->d_Dg),
+                     geo, coef, x, bvec, static_cast<T*>(op->d_partial));
+  HIPCHK(hipGetLastError());
+  return FUS_OK;
+}
+
+// b_internal = A x_internal  (all dofs: interior written by the block kernel, shared reduced)
+template <typename T, int P, int OP>
+static int apply_internal(fus_op* op, const T* coef, const T* x, T* bvec)
+{
+  fus_ctx* c = op->ctx;
+  {
+    ProfScope ps(c, OP == OP_STIFFNESS ? "stiffness" : "mass");
+    const T* geo = static_cast<const T*>(OP == OP_STIFFNESS ? op->d_G : op->d_detJ);
+    FUSCHK((launch_block_op<T, P, OP>(op, geo, coef, x, bvec)));
+  }
+  if (op->L.n_shared > 0)
+  {
+    ProfScope ps(c, "shared");
+    hipLaunchKernelGGL((k_shared_reduce<T>), dim3(nblk(op->L.n_shared)), dim3(256), 0, c->stream,
+                       op->L.n_shared, op->d_sh_ptr, op->d_sh_pairs,
+                       static_cast<const T*>(op->d_partial), bvec + op->L.n_int_pad);
+    HIPCHK(hipGetLastError());
+  }
+  return FUS_OK;
+}
+
+template <typename T>
+static int halo_sum(fus_op* op, T* vec)
+{
+  fus_ctx* c = op->ctx;
+  if (op->neigh.empty())
+    return FUS_OK;
+  if (!c->comm)
+    return fail(FUS_ERR_STATE, "neighbours set but fus_comm_init was not called");
+  ProfScope ps(c, "halo");
+  hipStream_t st = c->stream;
+  const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
+  for (auto& nb : op->neigh)
+    hipLaunchKernelGGL((k_pack<T>), dim3(nblk(nb.count)), dim3(256), 0, st, nb.count, nb.d_idx, vec,
+                       static_cast<T*>(nb.d_send));
+  hipLaunchKernelGGL((k_pack<T>), dim3(nblk(op->n_uidx)), dim3(256), 0, st, op->n_uidx, op->d_uidx,
+                     vec, static_cast<T*>(op->d_own));
+  NCCLCHK(ncclGroupStart());
+  for (auto& nb : op->neigh)
+  {
+    NCCLCHK(ncclSend(nb.d_send, nb.count, dt, nb.rank, c->comm, st));
+    NCCLCHK(ncclRecv(nb.d_recv, nb.count, dt, nb.rank, c->comm, st));
+  }
+  NCCLCHK(ncclGroupEnd());
+  // every sharer sums the partials in ascending rank order -> identical bits on all ranks
+  hipLaunchKernelGGL((k_zero_at<T>), dim3(nblk(op->n_uidx)), dim3(256), 0, st, op->n_uidx,
+                     op->d_uidx, vec);
+  bool own_added = false;
+  for (auto& nb : op->neigh)  // sorted by rank at set_neighbours
+  {
+    if (!own_added && nb.rank > c->rank)
+    {
+      hipLaunchKernelGGL((k_add_at<T>), dim3(nblk(op->n_uidx)), dim3(256), 0, st, op->n_uidx,
+                         op->d_uidx, static_cast<const T*>(op->d_own), vec);
+      own_added = true;
+    }
+    hipLaunchKernelGGL((k_add_at<T>), dim3(nblk(nb.count)), dim3(256), 0, st, nb.count, nb.d_idx,
+                       static_cast<const T*>(nb.d_recv), vec);
+  }
+  if (!own_added)
+    hipLaunchKernelGGL((k_add_at<T>), dim3(nblk(op->n_uidx)), dim3(256), 0, st, op->n_uidx,
+                       op->d_uidx, static_cast<const T*>(op->d_own), vec);
+  HIPCHK(hipGetLastError());
+  return FUS_OK;
+}
+
+template <typename T, int P>
+static int op_setup_device(fus_op* op)
+{
+  constexpr int N = P + 1, Nd = N * N * N;
+  fus_ctx* c = op->ctx;
+  hipStream_t st = c->stream;
+  Layout& L = op->L;
+  auto& pool = op->allocs;
+
+  std::vector<ShapeDev> shapes(L.shapes.size());
+  for (size_t i = 0; i < shapes.size(); ++i)
+  {
+    shapes[i].nelem = L.shapes[i].nelem, shapes[i].nloc = L.shapes[i].nloc;
+    shapes[i].nint = L.shapes[i].nint, shapes[i].nrounds = L.shapes[i].nrounds;
+    shapes[i].rounds_off = L.shapes[i].rounds_off, shapes[i].ldm_off = L.shapes[i].ldm_off;
+  }
+  int32_t *d_blk_shape, *d_elem_off, *d_int_off, *d_sh_gidx;
+  int64_t* d_sh_off;
+  ShapeDev* d_shapes;
+  int16_t* d_rounds;
+  uint16_t* d_ldm;
+  FUSCHK(upload(pool, &d_blk_shape, L.blk_shape, st));
+  FUSCHK(upload(pool, &d_shapes, shapes, st));
+  FUSCHK(upload(pool, &d_elem_off, L.blk_elem_off, st));
+  FUSCHK(upload(pool, &d_int_off, L.blk_int_off, st));
+  FUSCHK(upload(pool, &d_sh_off, L.blk_sh_off, st));
+  FUSCHK(upload(pool, &d_sh_gidx, L.sh_gidx, st));
+  FUSCHK(upload(pool, &d_rounds, L.rounds, st));
+  FUSCHK(upload(pool, &d_ldm, L.ldm, st));
+  FUSCHK(upload(pool, &op->d_cell_perm, L.cell_perm, st));
+  FUSCHK(upload(pool, &op->d_dof_perm, L.dof_perm, st));
+  FUSCHK(upload(pool, &op->d_sh_ptr, L.sh_ptr, st));
+  FUSCHK(upload(pool, &op->d_sh_pairs, L.sh_pairs, st));
+  op->A.blk_shape = d_blk_shape, op->A.shapes = d_shapes, op->A.blk_elem_off = d_elem_off;
+  op->A.blk_int_off = d_int_off, op->A.blk_sh_off = d_sh_off, op->A.sh_gidx = d_sh_gidx;
+  op->A.rounds = d_rounds, op->A.ldm = d_ldm, op->A.nblocks = L.nblocks;
+  op->A.lds_nloc = (L.max_nloc + 1) & ~1;
+  op->A.waves = L.waves;
+  op->lds_bytes = (size_t)2 * op->A.lds_nloc * sizeof(T) + (size_t)L.slots * 2 * Nd * sizeof(T);
+  if (op->lds_bytes > 160 * 1024)
+    return fail(FUS_ERR_LIMIT, "block does not fit 160 KB of LDS; lower block_elems");
+
+  std::vector<T> Dg(N * N);
+  for (int i = 0; i < N * N; ++i)
+    Dg[i] = (T)op->D[i];
+  T* d_Dg;
+  FUSCHK(upload(pool, &d_Dg, Dg, st));
+  op->d_Dg = d_Dg;
+
+  // geometry on the device, straight into the streaming layouts
+  T* d_xg;
+  int32_t* d_xdm;
+  double *d_pts, *d_wts;
+  std::vector<void*> tmp;
+  FUSCHK(dalloc(tmp, &d_xg, (size_t)op->nnodes * 3));
+  HIPCHK(hipMemcpyAsync(d_xg, op->h_geom_x.data(), (size_t)op->nnodes * 3 * sizeof(T),
+                        hipMemcpyHostToDevice, st));
+  FUSCHK(upload(tmp, &d_xdm, op->h_geom_dm, st));
+  FUSCHK(upload(tmp, &d_pts, op->nodes, st));
+  FUSCHK(upload(tmp, &d_wts, op->wts, st));
+  FUSCHK(dalloc_bytes(pool, &op->d_G, (size_t)op->ncells * 6 * Nd * sizeof(T), false, st));
+  FUSCHK(dalloc_bytes(pool, &op->d_detJ, (size_t)op->ncells * Nd * sizeof(T), false, st));
+  hipLaunchKernelGGL((k_geometry<T, N>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st, op->ncells,
+                     op->d_cell_perm, d_xg, d_xdm, d_pts, d_wts, static_cast<T*>(op->d_G),
+                     static_cast<T*>(op->d_detJ));
+  HIPCHK(hipGetLastError());
+
+  FUSCHK(dalloc_bytes(pool, &op->d_partial, (size_t)L.npairs * sizeof(T), true, st));
+  FUSCHK(dalloc_bytes(pool, &op->d_tmp_x, (size_t)L.n_internal * sizeof(T), true, st));
+  FUSCHK(dalloc_bytes(pool, &op->d_tmp_b, (size_t)L.n_internal * sizeof(T), true, st));
+  FUSCHK(dalloc_bytes(pool, &op->d_tmp_c, (size_t)op->ndofs * sizeof(T), true, st));
+  FUSCHK(dalloc_bytes(pool, &op->d_tmp_coef, (size_t)op->ncells * sizeof(T) * 2, true, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (void* q : tmp)
+    (void)hipFree(q);
+  return FUS_OK;
+}
+
+// y += A(coeffs) x with caller-numbered vectors (the reference operator call)
+template <typename T, int P, int OP>
+static int op_apply(fus_op* op, const void* x, const void* coeffs, void* y, int space)
+{
+  fus_ctx* c = op->ctx;
+  hipStream_t st = c->stream;
+  Layout& L = op->L;
+  T* xin = static_cast<T*>(op->d_tmp_x);
+  T* bint = static_cast<T*>(op->d_tmp_b);
+  T* tc = static_cast<T*>(op->d_tmp_c);
+  T* coef_c = static_cast<T*>(op->d_tmp_coef);
+  T* coef_i = coef_c + op->ncells;
+  const T* xc = static_cast<const T*>(x);
+  const T* cc = static_cast<const T*>(coeffs);
+  if (space == FUS_HOST)
+  {
+    HIPCHK(hipMemcpyAsync(tc, x, op->ndofs * sizeof(T), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(coef_c, coeffs, op->ncells * sizeof(T), hipMemcpyHostToDevice, st));
+    xc = tc, cc = coef_c;
+  }
+  hipLaunchKernelGGL((k_to_internal<T>), dim3(nblk(op->ndofs)), dim3(256), 0, st, op->ndofs,
+                     op->d_dof_perm, xc, xin);
+  hipLaunchKernelGGL((k_cells_to_internal<T>), dim3(nblk(op->ncells)), dim3(256), 0, st, op->ncells,
+                     op->d_cell_perm, cc, coef_i);
+  FUSCHK((apply_internal<T, P, OP>(op, coef_i, xin, bint)));
+  if (space == FUS_HOST)
+  {
+    HIPCHK(hipMemcpyAsync(tc, y, op->ndofs * sizeof(T), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((k_from_internal<T, 1>), dim3(nblk(op->ndofs)), dim3(256), 0, st, op->ndofs,
+                       op->d_dof_perm, bint, tc);
+    HIPCHK(hipMemcpyAsync(y, tc, op->ndofs * sizeof(T), hipMemcpyDeviceToHost, st));
+  }
+  else
+    hipLaunchKernelGGL((k_from_internal<T, 1>), dim3(nblk(op->ndofs)), dim3(256), 0, st, op->ndofs,
+                       op->d_dof_perm, bint, static_cast<T*>(y));
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  (void)L;
+  return FUS_OK;
+}
+
+template <typename T, int P>
+static int op_get_geometry(fus_op* op, void* G, void* detJ)
+{
+  constexpr int N = P + 1, Nd = N * N * N;
+  hipStream_t st = op->ctx->stream;
+  std::vector<void*> tmp;
+  T *dG = nullptr, *dd = nullptr;
+  if (G)
+    FUSCHK(dalloc(tmp, &dG, (size_t)op->ncells * Nd * 6));
+  if (detJ)
+    FUSCHK(dalloc(tmp, &dd, (size_t)op->ncells * Nd));
+  hipLaunchKernelGGL((k_geometry_export<T, N>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st,
+                     op->ncells, op->d_cell_perm, static_cast<const T*>(op->d_G),
+                     static_cast<const T*>(op->d_detJ), dG, dd);
+  HIPCHK(hipGetLastError());
+  if (G)
+    HIPCHK(hipMemcpyAsync(G, dG, (size_t)op->ncells * Nd * 6 * sizeof(T), hipMemcpyDeviceToHost, st));
+  if (detJ)
+    HIPCHK(hipMemcpyAsync(detJ, dd, (size_t)op->ncells * Nd * sizeof(T), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  for (void* q : tmp)
+    (void)hipFree(q);
+  return FUS_OK;
+}
+
+// Host builder of the diagonal facet weights (setup)
+template <typename T>
+static void facet_diag_host(const fus_op* op, int64_t nfacets, const int32_t* fc, const int32_t* fl,
+                            const T* cellcoef, T* out)
+{
+  static const int axis3[6] = {2, 1, 0, 0, 1, 2}, side3[6] = {0, 0, 0, 1, 1, 1};
+  const int N = op->N, Nd = op->Nd;
+  const T* xg = reinterpret_cast<const T*>(op->h_geom_x.data());
+  int i_lo = 0, i_hi = 0;
+  for (int i = 0; i < N; ++i)
+  {
+    if (op->nodes[i] < op->nodes[i_lo])
+      i_lo = i;
+    if (op->nodes[i] > op->nodes[i_hi])
+      i_hi = i;
+  }
+  for (int64_t f = 0; f < nfacets; ++f)
+  {
+    const int64_t cell = fc[f];
+    const int ax = axis3[fl[f]], sd = side3[fl[f]];
+    const int d1 = (ax + 1) % 3, d2 = (ax + 2) % 3;
+    T cd[8][3];
+    for (int v = 0; v < 8; ++v)
+      for (int j = 0; j < 3; ++j)
+        cd[v][j] = xg[3 * (int64_t)op->h_geom_dm[cell * 8 + v] + j];
+    for (int a = 0; a < N; ++a)
+      for (int b = 0; b < N; ++b)
+      {
+        int idx[3];
+        idx[ax] = sd ? i_hi : i_lo, idx[d1] = a, idx[d2] = b;
+        T J[3][3];
+        jacobian3<T>(cd, op->nodes[idx[0]], op->nodes[idx[1]], op->nodes[idx[2]], J);
+        const T t1[3] = {J[0][d1], J[1][d1], J[2][d1]}, t2[3] = {J[0][d2], J[1][d2], J[2][d2]};
+        const T n0 = t1[1] * t2[2] - t1[2] * t2[1], n1 = t1[2] * t2[0] - t1[0] * t2[2],
+                n2 = t1[0] * t2[1] - t1[1] * t2[0];
+        const T area = (T)std::sqrt((double)(n0 * n0 + n1 * n1 + n2 * n2));
+        const int li = (idx[0] * N + idx[1]) * N + idx[2];
+        out[op->h_dofmap[cell * Nd + li]] += cellcoef[cell] * area * (T)(op->wts[a] * op->wts[b]);
+      }
+  }
+}
+
+template <typename T, int P>
+static int model_setup(fus_model* m, const void* c0_, const void* rho0_, int64_t nfacets,
+                       const int32_t* fc, const int32_t* fl, const int32_t* ft)
+{
+  fus_op* op = m->op;
+  fus_ctx* c = m->ctx;
+  hipStream_t st = c->stream;
+  const Layout& L = op->L;
+  const int64_t n = L.n_internal;
+  const T* c0 = static_cast<const T*>(c0_);
+  const T* rho0 = static_cast<const T*>(rho0_);
+  auto& pool = m->allocs;
+  for (void** v : {&m->u0, &m->v0, &m->u_, &m->v_, &m->un, &m->vn, &m->b, &m->minv, &m->m})
+    FUSCHK(dalloc_bytes(pool, v, n * sizeof(T), true, st));
+
+  // operator coefficient -1/rho (Linear.hpp:154-155) and mass coefficient 1/(rho c^2)
+  // (forms.py:36), internal element order
+  std::vector<T> coef(op->ncells), mcoef(op->ncells);
+  for (int64_t e = 0; e < op->ncells; ++e)
+  {
+    const int64_t cell = L.cell_perm[e];
+    coef[e] = T(-1.0) / rho0[cell];
+    mcoef[e] = T(1.0) / rho0[cell] / c0[cell] / c0[cell];
+  }
+  T *d_coef, *d_mcoef;
+  FUSCHK(upload(pool, &d_coef, coef, st));
+  FUSCHK(upload(pool, &d_mcoef, mcoef, st));
+  m->coef = d_coef;
+
+  // lumped mass: m = M(1/(rho c^2)) 1  (Linear.hpp:127-134) + sum over sharers (scatter_rev :134)
+  T* ones = static_cast<T*>(m->un);
+  hipLaunchKernelGGL((k_fill<T>), dim3(1024), dim3(256), 0, st, n, ones, T(1));
+  FUSCHK((apply_internal<T, P, OP_MASS>(op, d_mcoef, ones, static_cast<T*>(m->m))));
+  FUSCHK(halo_sum<T>(op, static_cast<T*>(m->m)));
+  hipLaunchKernelGGL((k_reciprocal<T>), dim3(nblk(n)), dim3(256), 0, st, n,
+                     static_cast<const T*>(m->m), static_cast<T*>(m->minv));
+  HIPCHK(hipMemsetAsync(m->un, 0, n * sizeof(T), st));
+
+  // boundary weights: tag 1 -> (1/rho) w_f, tag 2 -> (1/(rho c)) w_f (forms.py:38-39)
+  std::vector<T> src(op->ndofs, T(0)), absb(op->ndofs, T(0)), cs(op->ncells), ca(op->ncells);
+  for (int64_t k = 0; k < op->ncells; ++k)
+    cs[k] = T(1.0) / rho0[k], ca[k] = T(1.0) / rho0[k] / c0[k];
+  std::vector<int32_t> c1, l1, c2, l2;
+  for (int64_t f = 0; f < nfacets; ++f)
+  {
+    if (fc[f] < 0 || fc[f] >= op->ncells || fl[f] < 0 || fl[f] > 5)
+      return fail(FUS_ERR_ARG, "facet (cell, local facet) out of range");
+    if (ft[f] == 1)
+      c1.push_back(fc[f]), l1.push_back(fl[f]);
+    else if (ft[f] == 2)
+      c2.push_back(fc[f]), l2.push_back(fl[f]);
+  }
+  facet_diag_host<T>(op, (int64_t)c1.size(), c1.data(), l1.data(), cs.data(), src.data());
+  facet_diag_host<T>(op, (int64_t)c2.size(), c2.data(), l2.data(), ca.data(), absb.data());
+  if (!op->neigh.empty())
+  {
+    // facet contributions to interface dofs are summed over the sharing ranks like m
+    T* tmpc = static_cast<T*>(op->d_tmp_c);
+    T* tmpi = static_cast<T*>(op->d_tmp_x);
+    for (std::vector<T>* vec : {&src, &absb})
+    {
+      HIPCHK(hipMemcpyAsync(tmpc, vec->data(), op->ndofs * sizeof(T), hipMemcpyHostToDevice, st));
+      HIPCHK(hipMemsetAsync(tmpi, 0, n * sizeof(T), st));
+      hipLaunchKernelGGL((k_to_internal<T>), dim3(nblk(op->ndofs)), dim3(256), 0, st, op->ndofs,
+                         op->d_dof_perm, tmpc, tmpi);
+      FUSCHK(halo_sum<T>(op, tmpi));
+      hipLaunchKernelGGL((k_from_internal<T, 0>), dim3(nblk(op->ndofs)), dim3(256), 0, st,
+                         op->ndofs, op->d_dof_perm, tmpi, tmpc);
+      HIPCHK(hipMemcpyAsync(vec->data(), tmpc, op->ndofs * sizeof(T), hipMemcpyDeviceToHost, st));
+      HIPCHK(hipStreamSynchronize(st));
+    }
+  }
+  std::vector<int32_t> bidx;
+  std::vector<T> bsrc, babs;
+  for (int64_t g = 0; g < op->ndofs; ++g)
+    if (src[g] != T(0) || absb[g] != T(0))
+    {
+      bidx.push_back(L.dof_perm[g]);
+      bsrc.push_back(src[g]);
+      babs.push_back(absb[g]);
+    }
+  m->nb = (int64_t)bidx.size();
+  T *d_bsrc, *d_babs;
+  FUSCHK(upload(pool, &m->d_bidx, bidx, st));
+  FUSCHK(upload(pool, &d_bsrc, bsrc, st));
+  FUSCHK(upload(pool, &d_babs, babs, st));
+  m->d_bsrc = d_bsrc, m->d_babs = d_babs;
+  HIPCHK(hipStreamSynchronize(st));
+  return FUS_OK;
+}
+
+// One classical RK4 step (Linear.hpp:273-295), state in (u0, v0) on entry and exit.
+template <typename T, int P>
+static int model_step(fus_model* m, double t_, double dt_)
+{
+  fus_op* op = m->op;
+  fus_ctx* c = m->ctx;
+  hipStream_t st = c->stream;
+  const int64_t n = op->L.n_internal;
+  const T t = (T)t_, dt = (T)dt_;
+  const T a_runge[5] = {0.0, 0.5, 0.5, 1.0, 0.0};
+  const T b_runge[4] = {(T)(1.0 / 6.0), (T)(1.0 / 3.0), (T)(1.0 / 3.0), (T)(1.0 / 6.0)};
+  const T c_runge[4] = {0.0, 0.5, 0.5, 1.0};
+  const T freq = (T)m->freq, p0 = (T)m->amp, s0 = (T)m->speed;
+  const T w0 = (T)(2 * M_PI * m->freq);
+  const T period = (T)(1.0 / m->freq), window_length = (T)4.0;
+  T *u0 = static_cast<T*>(m->u0), *v0 = static_cast<T*>(m->v0), *u_ = static_cast<T*>(m->u_),
+    *v_ = static_cast<T*>(m->v_), *un = static_cast<T*>(m->un), *vn = static_cast<T*>(m->vn),
+    *b = static_cast<T*>(m->b);
+  const T* minv = static_cast<const T*>(m->minv);
+  const unsigned grid = (unsigned)std::min<int64_t>(nblk(n / (16 / sizeof(T))), 256 * 16);
+  for (int i = 0; i < 4; ++i)
+  {
+    const T tn = t + c_runge[i] * dt;
+    // source scalar (Linear.hpp:185-192)
+    T window;
+    if (tn < period * window_length)
+      window = (T)(0.5 * (1.0 - std::cos((double)(freq * (T)M_PI * tn / window_length))));
+    else
+      window = 1.0;
+    const T gval = window * p0 * w0 / s0 * (T)std::cos((double)(w0 * tn));
+    const T* ustage = (i == 0) ? u0 : un;  // a_0 = 0: un == u0, vn == v0
+    T* vstage = (i == 0) ? v0 : vn;
+    FUSCHK((apply_internal<T, P, OP_STIFFNESS>(op, static_cast<const T*>(m->coef), ustage, b)));
+    FUSCHK(halo_sum<T>(op, b));
+    if (m->nb > 0)
+    {
+      ProfScope ps(c, "boundary");
+      hipLaunchKernelGGL((k_boundary<T>), dim3(nblk(m->nb)), dim3(256), 0, st, m->nb, m->d_bidx,
+                         static_cast<const T*>(m->d_bsrc), static_cast<const T*>(m->d_babs), gval,
+                         vstage, b);
+    }
+    {
+      ProfScope ps(c, "stage");
+      const T adt = dt * a_runge[i + 1], bdt = dt * b_runge[i];
+      switch (i)
+      {
+      case 0:
+        hipLaunchKernelGGL((k_stage<T, 0>), dim3(grid), dim3(256), 0, st, n, b, minv, vn, un, u0,
+                           v0, u_, v_, adt, bdt);
+        break;
+      case 3:
+        hipLaunchKernelGGL((k_stage<T, 3>), dim3(grid), dim3(256), 0, st, n, b, minv, vn, un, u0,
+                           v0, u_, v_, adt, bdt);
+        break;
+      default:
+        hipLaunchKernelGGL((k_stage<T, 1>), dim3(grid), dim3(256), 0, st, n, b, minv, vn, un, u0,
+                           v0, u_, v_, adt, bdt);
+      }
+    }
+  }
+  HIPCHK(hipGetLastError());
+  return FUS_OK;
+}
+
+template <typename T>
+static int model_getset(fus_model* m, int which, void* host_or_dev, int space, bool set)
+{
+  fus_op* op = m->op;
+  hipStream_t st = m->ctx->stream;
+  T* vec = static_cast<T*>(which == FUS_U ? m->u0 : m->v0);
+  T* tc = static_cast<T*>(op->d_tmp_c);
+  if (set)
+  {
+    const T* src = static_cast<const T*>(host_or_dev);
+    if (space == FUS_HOST)
+    {
+      HIPCHK(hipMemcpyAsync(tc, host_or_dev, op->ndofs * sizeof(T), hipMemcpyHostToDevice, st));
+      src = tc;
+    }
+    hipLaunchKernelGGL((k_to_internal<T>), dim3(nblk(op->ndofs)), dim3(256), 0, st, op->ndofs,
+                       op->d_dof_perm, src, vec);
+  }
+  else
+  {
+    T* dst = space == FUS_HOST ? tc : static_cast<T*>(host_or_dev);
+    hipLaunchKernelGGL((k_from_internal<T, 0>), dim3(nblk(op->ndofs)), dim3(256), 0, st, op->ndofs,
+                       op->d_dof_perm, vec, dst);
+    if (space == FUS_HOST)
+      HIPCHK(hipMemcpyAsync(host_or_dev, tc, op->ndofs * sizeof(T), hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(hipGetLastError());
+  HIPCHK(hipStreamSynchronize(st));
+  return FUS_OK;
+}
+
+// -------------------------------------------------------------------------------------------------
+// dispatch over (dtype, P)
+// -------------------------------------------------------------------------------------------------
+#define FUS_DISPATCH_P(T, P_, CALL)                                                                \
+  switch (P_)                                                                                      \
+  {                                                                                                \
+  case 2: { constexpr int PP = 2; return CALL; }                                                   \
+  case 3: { constexpr int PP = 3; return CALL; }                                                   \
+  case 4: { constexpr int PP = 4; return CALL; }                                                   \
+  case 5: { constexpr int PP = 5; return CALL; }                                                   \
+  case 6: { constexpr int PP = 6; return CALL; }                                                   \
+  case 7: { constexpr int PP = 7; return CALL; }                                                   \
+  default: return fail(FUS_ERR_ARG, "unsupported polynomial degree (2..7)");                       \
+  }
+#define FUS_DISPATCH(dtype_, P_, CALL)                                                             \
+  do                                                                                               \
+  {                                                                                                \
+    if ((dtype_) == FUS_F64)                                                                       \
+    {                                                                                              \
+      typedef double TT;                                                                           \
+      FUS_DISPATCH_P(TT, P_, CALL)                                                                 \
+    }                                                                                              \
+    else                                                                                           \
+    {                                                                                              \
+      typedef float TT;                                                                            \
+      FUS_DISPATCH_P(TT, P_, CALL)                                                                 \
+    }                                                                                              \
+  } while (0)
+
+static int d_op_setup(fus_op* op) { FUS_DISPATCH(op->dtype, op->P, (op_setup_device<TT, PP>(op))); }
+static int d_op_apply(fus_op* op, int kind, const void* x, const void* cf, void* y, int space)
+{
+  if (kind == OP_STIFFNESS)
+    FUS_DISPATCH(op->dtype, op->P, (op_apply<TT, PP, OP_STIFFNESS>(op, x, cf, y, space)));
+  else
+    FUS_DISPATCH(op->dtype, op->P, (op_apply<TT, PP, OP_MASS>(op, x, cf, y, space)));
+}
+static int d_op_get_geometry(fus_op* op, void* G, void* dJ)
+{
+  FUS_DISPATCH(op->dtype, op->P, (op_get_geometry<TT, PP>(op, G, dJ)));
+}
+static int d_model_setup(fus_model* m, const void* c0, const void* rho0, int64_t nf,
+                         const int32_t* fc, const int32_t* fl, const int32_t* ft)
+{
+  FUS_DISPATCH(m->op->dtype, m->op->P, (model_setup<TT, PP>(m, c0, rho0, nf, fc, fl, ft)));
+}
+static int d_model_step(fus_model* m, double t, double dt)
+{
+  FUS_DISPATCH(m->op->dtype, m->op->P, (model_step<TT, PP>(m, t, dt)));
+}
+
+// -------------------------------------------------------------------------------------------------
+// C ABI
+// -------------------------------------------------------------------------------------------------
+extern "C"
+{
+
+const char* fus_last_error(void) { return g_err.c_str(); }
+int fus_version(void) { return 1; }
+
+int fus_init(int device, fus_ctx** out)
+{
+  if (!out)
+    return fail(FUS_ERR_ARG, "null ctx pointer");
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(FUS_ERR_HIP, "no HIP device: libfusmi has no CPU fallback");
+  if (device < 0 || device >= ndev)
+    return fail(FUS_ERR_ARG, "device index out of range");
+  HIPCHK(hipSetDevice(device));
+  auto* c = new fus_ctx();
+  c->device = device;
+  HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  *out = c;
+  return FUS_OK;
+}
+
+int fus_finalize(fus_ctx* c)
+{
+  if (!c)
+    return FUS_OK;
+  (void)hipSetDevice(c->device);
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& kv : c->profs)
+    for (auto& ev : kv.second.ev)
+      (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
+  if (c->comm)
+    ncclCommDestroy(c->comm);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  return FUS_OK;
+}
+
+int fus_synchronize(fus_ctx* c)
+{
+  HIPCHK(hipStreamSynchronize(c->stream));
+  return FUS_OK;
+}
+
+int fus_set_option(fus_ctx* c, const char* key, int64_t value)
+{
+  if (!c || !key)
+    return fail(FUS_ERR_ARG, "null argument");
+  if (!strcmp(key, "block_elems"))
+  {
+    if (value < 1 || value > 4096)
+      return fail(FUS_ERR_ARG, "block_elems out of range");
+    c->block_elems = (int)value;
+  }
+  else if (!strcmp(key, "waves"))
+  {
+    if (value != 1 && value != 2 && value != 4)
+      return fail(FUS_ERR_ARG, "waves must be 1, 2 or 4");
+    c->waves = (int)value;
+  }
+  else
+    return fail(FUS_ERR_ARG, std::string("unknown option ") + key);
+  return FUS_OK;
+}
+
+int fus_comm_unique_id(void* id128)
+{
+  static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+  ncclUniqueId id;
+  NCCLCHK(ncclGetUniqueId(&id));
+  memcpy(id128, &id, 128);
+  return FUS_OK;
+}
+
+int fus_comm_init(fus_ctx* c, int rank, int nranks, const void* id128)
+{
+  if (!c || nranks < 1 || rank < 0 || rank >= nranks)
+    return fail(FUS_ERR_ARG, "bad rank/nranks");
+  c->rank = rank, c->nranks = nranks;
+  if (nranks == 1)
+    return FUS_OK;
+  ncclUniqueId id;
+  memcpy(&id, id128, 128);
+  HIPCHK(hipSetDevice(c->device));
+  NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
+  return FUS_OK;
+}
+
+int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_t ndofs,
+                  const int32_t* tensor_dofmap, const double* nodes1d, const void* geom_x,
+                  int64_t nnodes, const int32_t* geom_dofmap, int geom_order, fus_op** out)
+{
+  if (!c || !out || !tensor_dofmap || !nodes1d || !geom_x || !geom_dofmap)
+    return fail(FUS_ERR_ARG, "null argument");
+  if (tdim != 3)
+    return fail(FUS_ERR_ARG, "only tdim = 3 (hexahedra) is offloaded");
+  if (P < 2 || P > 7)
+    return fail(FUS_ERR_ARG, "unsupported polynomial degree (2..7)");
+  if (dtype != FUS_F64 && dtype != FUS_F32)
+    return fail(FUS_ERR_ARG, "dtype must be FUS_F32 or FUS_F64");
+  if (geom_order != 1)
+    return fail(FUS_ERR_ARG, "only first-order (trilinear) geometry is supported");
+  if (ncells <= 0 || ndofs <= 0 || nnodes <= 0)
+    return fail(FUS_ERR_ARG, "empty mesh");
+  const int N = P + 1;
+  if (!is_gll_node_set(N, nodes1d))
+    return fail(FUS_ERR_ARG, "nodes1d are not the GLL points of [0,1]");
+  HIPCHK(hipSetDevice(c->device));
+  std::unique_ptr<fus_op> op(new fus_op());
+  op->ctx = c, op->P = P, op->N = N, op->Nd = N * N * N, op->dtype = dtype;
+  op->ts = dtype == FUS_F64 ? 8 : 4;
+  op->ncells = ncells, op->ndofs = ndofs, op->nnodes = nnodes;
+  op->nodes.assign(nodes1d, nodes1d + N);
+  op->wts = gll_weights_at(N, nodes1d);
+  op->D = dphi_table(N, nodes1d);
+  op->h_geom_x.assign(static_cast<const char*>(geom_x),
+                      static_cast<const char*>(geom_x) + (size_t)nnodes * 3 * op->ts);
+  op->h_geom_dm.assign(geom_dofmap, geom_dofmap + ncells * 8);
+  op->h_dofmap.assign(tensor_dofmap, tensor_dofmap + ncells * op->Nd);
+  for (int64_t k = 0; k < ncells * 8; ++k)
+    if (geom_dofmap[k] < 0 || geom_dofmap[k] >= nnodes)
+      return fail(FUS_ERR_ARG, "geometry dofmap entry out of range");
+  // centroids for the block partitioner
+  std::vector<double> cen((size_t)ncells * 3, 0.0);
+  for (int64_t cidx = 0; cidx < ncells; ++cidx)
+    for (int v = 0; v < 8; ++v)
+      for (int j = 0; j < 3; ++j)
+      {
+        const size_t k = 3 * (size_t)geom_dofmap[cidx * 8 + v] + j;
+        cen[3 * cidx + j] += 0.125 * (dtype == FUS_F64 ? static_cast<const double*>(geom_x)[k]
+                                                       : (double)static_cast<const float*>(geom_x)[k]);
+      }
+  // blocks must fit the CU's 160 KB of LDS: halve the block size until they do
+  for (int be = c->block_elems;; be = (be + 1) / 2)
+  {
+    std::string err = build_layout(op->L, P, ncells, ndofs, tensor_dofmap, cen.data(), be, c->waves);
+    const bool too_big = err.empty() ? op->L.lds_bytes(op->ts) + 64 > 160 * 1024
+                                     : err.find("65535") != std::string::npos;
+    if (too_big && be > 1)
+      continue;
+    if (!err.empty())
+      return fail(FUS_ERR_ARG, "layout: " + err);
+    break;
+  }
+  int r = d_op_setup(op.get());
+  if (r != FUS_OK)
+  {
+    for (void* q : op->allocs)
+      (void)hipFree(q);
+    return r;
+  }
+  *out = op.release();
+  return FUS_OK;
+}
+
+int fus_op_destroy(fus_op* op)
+{
+  if (!op)
+    return FUS_OK;
+  (void)hipSetDevice(op->ctx->device);
+  (void)hipStreamSynchronize(op->ctx->stream);
+  for (void* q : op->allocs)
+    (void)hipFree(q);
+  for (auto& nb : op->neigh)
+    (void)hipFree(nb.d_idx), (void)hipFree(nb.d_send), (void)hipFree(nb.d_recv);
+  (void)hipFree(op->d_uidx), (void)hipFree(op->d_own);
+  delete op;
+  return FUS_OK;
+}
+
+int fus_stiffness_apply(fus_op* op, const void* x, const void* coeffs, void* y, int space)
+{
+  if (!op || !x || !coeffs || !y)
+    return fail(FUS_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(op->ctx->device));
+  return d_op_apply(op, OP_STIFFNESS, x, coeffs, y, space);
+}
+
+int fus_mass_apply(fus_op* op, const void* x, const void* coeffs, void* y, int space)
+{
+  if (!op || !x || !coeffs || !y)
+    return fail(FUS_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(op->ctx->device));
+  return d_op_apply(op, OP_MASS, x, coeffs, y, space);
+}
+
+int fus_op_get_geometry(fus_op* op, void* G, void* detJ)
+{
+  if (!op)
+    return fail(FUS_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(op->ctx->device));
+  return d_op_get_geometry(op, G, detJ);
+}
+
+int fus_op_get_tables(fus_op* op, double* weights, double* dphi)
+{
+  if (!op)
+    return fail(FUS_ERR_ARG, "null argument");
+  if (weights)
+    memcpy(weights, op->wts.data(), sizeof(double) * op->N);
+  if (dphi)
+    memcpy(dphi, op->D.data(), sizeof(double) * op->N * op->N);
+  return FUS_OK;
+}
+
+static void layout_info(const Layout& L, size_t ts, int64_t out[8])
+{
+  out[0] = L.nblocks, out[1] = L.n_interior, out[2] = L.n_shared, out[3] = L.npairs;
+  out[4] = L.max_nloc, out[5] = (int64_t)L.shapes.size();
+  out[6] = (int64_t)((size_t)2 * ((L.max_nloc + 1) & ~1) * ts + (size_t)L.slots * 2 * L.Nd * ts);
+  out[7] = L.n_internal;
+}
+
+int fus_op_info(fus_op* op, int64_t out[8])
+{
+  if (!op || !out)
+    return fail(FUS_ERR_ARG, "null argument");
+  layout_info(op->L, op->ts, out);
+  return FUS_OK;
+}
+
+int fus_layout_check(int P, int64_t ncells, int64_t ndofs, const int32_t* tensor_dofmap,
+                     const double* centroids, int block_elems, int waves, int64_t out[8])
+{
+  if (!tensor_dofmap || !centroids || !out)
+    return fail(FUS_ERR_ARG, "null argument");
+  Layout L;
+  std::string err = build_layout(L, P, ncells, ndofs, tensor_dofmap, centroids, block_elems, waves);
+  if (!err.empty())
+    return fail(FUS_ERR_ARG, "layout: " + err);
+  err = verify_layout(L, tensor_dofmap);
+  if (!err.empty())
+    return fail(FUS_ERR_STATE, "layout verification: " + err);
+  layout_info(L, 8, out);
+  return FUS_OK;
+}
+
+int fus_facet_diag(fus_op* op, int64_t nfacets, const int32_t* fc, const int32_t* fl,
+                   const void* cellcoef, void* out)
+{
+  if (!op || !out || (nfacets > 0 && (!fc || !fl || !cellcoef)))
+    return fail(FUS_ERR_ARG, "null argument");
+  for (int64_t f = 0; f < nfacets; ++f)
+    if (fc[f] < 0 || fc[f] >= op->ncells || fl[f] < 0 || fl[f] > 5)
+      return fail(FUS_ERR_ARG, "facet (cell, local facet) out of range");
+  if (op->dtype == FUS_F64)
+    facet_diag_host<double>(op, nfacets, fc, fl, static_cast<const double*>(cellcoef),
+                            static_cast<double*>(out));
+  else
+    facet_diag_host<float>(op, nfacets, fc, fl, static_cast<const float*>(cellcoef),
+                           static_cast<float*>(out));
+  return FUS_OK;
+}
+
+int fus_op_set_neighbours(fus_op* op, int nneigh, const int32_t* ranks, const int64_t* counts,
+                          const int32_t* dof_idx)
+{
+  if (!op || nneigh < 0 || (nneigh > 0 && (!ranks || !counts || !dof_idx)))
+    return fail(FUS_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(op->ctx->device));
+  hipStream_t st = op->ctx->stream;
+  std::vector<std::pair<int, int>> order;  // (rank, k)
+  std::vector<int64_t> off(nneigh + 1, 0);
+  for (int k = 0; k < nneigh; ++k)
+    off[k + 1] = off[k] + counts[k], order.emplace_back(ranks[k], k);
+  std::sort(order.begin(), order.end());
+  std::vector<int32_t> uniq;
+  for (auto& rk : order)
+  {
+    const int k = rk.second;
+    Neigh nb;
+    nb.rank = rk.first, nb.count = counts[k];
+    std::vector<int32_t> idx(nb.count);
+    for (int64_t j = 0; j < nb.count; ++j)
+    {
+      const int32_t g = dof_idx[off[k] + j];
+      if (g < 0 || g >= op->ndofs)
+        return fail(FUS_ERR_ARG, "shared dof index out of range");
+      idx[j] = op->L.dof_perm[g];
+      uniq.push_back(idx[j]);
+    }
+    HIPCHK(hipMalloc((void**)&nb.d_idx, std::max<size_t>(1, nb.count) * sizeof(int32_t)));
+    HIPCHK(hipMemcpyAsync(nb.d_idx, idx.data(), nb.count * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMalloc(&nb.d_send, std::max<size_t>(1, nb.count) * op->ts));
+    HIPCHK(hipMalloc(&nb.d_recv, std::max<size_t>(1, nb.count) * op->ts));
+    HIPCHK(hipStreamSynchronize(st));
+    op->neigh.push_back(nb);
+  }
+  std::sort(uniq.begin(), uniq.end());
+  uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+  op->n_uidx = (int64_t)uniq.size();
+  HIPCHK(hipMalloc((void**)&op->d_uidx, std::max<size_t>(1, uniq.size()) * sizeof(int32_t)));
+  HIPCHK(hipMemcpy(op->d_uidx, uniq.data(), uniq.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&op->d_own, std::max<size_t>(1, uniq.size()) * op->ts));
+  return FUS_OK;
+}
+
+int fus_model_create(fus_ctx* c, int kind, fus_op* op, const void* c0, const void* rho0,
+                     const void* delta0, const void* beta0, int64_t nfacets,
+                     const int32_t* facet_cells, const int32_t* facet_local,
+                     const int32_t* facet_tags, double freq, double amp, double speed,
+                     fus_model** out)
+{
+  if (!c || !op || !c0 || !rho0 || !out)
+    return fail(FUS_ERR_ARG, "null argument");
+  if (kind != FUS_LINEAR)
+    return fail(FUS_ERR_ARG, "only FUS_LINEAR is implemented");
+  if (delta0 || beta0)
+    return fail(FUS_ERR_ARG, "delta0/beta0 must be NULL for FUS_LINEAR");
+  if (nfacets > 0 && (!facet_cells || !facet_local || !facet_tags))
+    return fail(FUS_ERR_ARG, "null facet arrays");
+  if (!(freq > 0) || !(speed > 0))
+    return fail(FUS_ERR_ARG, "freq and speed must be positive");
+  HIPCHK(hipSetDevice(c->device));
+  std::unique_ptr<fus_model> m(new fus_model());
+  m->ctx = c, m->op = op, m->kind = kind, m->freq = freq, m->amp = amp, m->speed = speed;
+  int r = d_model_setup(m.get(), c0, rho0, nfacets, facet_cells, facet_local, facet_tags);
+  if (r != FUS_OK)
+  {
+    for (void* q : m->allocs)
+      (void)hipFree(q);
+    return r;
+  }
+  *out = m.release();
+  return FUS_OK;
+}
+
+int fus_model_destroy(fus_model* m)
+{
+  if (!m)
+    return FUS_OK;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipStreamSynchronize(m->ctx->stream);
+  for (void* q : m->allocs)
+    (void)hipFree(q);
+  delete m;
+  return FUS_OK;
+}
+
+int fus_model_init(fus_model* m)
+{
+  if (!m)
+    return fail(FUS_ERR_ARG, "null model");
+  HIPCHK(hipSetDevice(m->ctx->device));
+  const size_t bytes = (size_t)m->op->L.n_internal * m->op->ts;
+  for (void* v : {m->u0, m->v0, m->u_, m->v_, m->un, m->vn, m->b})
+    HIPCHK(hipMemsetAsync(v, 0, bytes, m->ctx->stream));
+  m->initialised = true;
+  return FUS_OK;
+}
+
+int fus_model_rk4(fus_model* m, double t0, double tf_, double dt_, int64_t* nsteps)
+{
+  if (!m)
+    return fail(FUS_ERR_ARG, "null model");
+  if (!m->initialised)
+    return fail(FUS_ERR_STATE, "fus_model_init (or fus_model_set) must be called before rk4");
+  if (!(dt_ > 0))
+    return fail(FUS_ERR_ARG, "dt must be positive");
+  HIPCHK(hipSetDevice(m->ctx->device));
+  int64_t step = 0;
+  if (m->op->dtype == FUS_F64)
+  {
+    double t = t0, tf = tf_, dt = dt_;
+    while (t < tf)
+    {
+      dt = std::min(dt, tf - t);
+      FUSCHK(d_model_step(m, t, dt));
+      t += dt;
+      ++step;
+    }
+  }
+  else
+  {
+    float t = (float)t0, tf = (float)tf_, dt = (float)dt_;
+    while (t < tf)
+    {
+      dt = std::min(dt, tf - t);
+      FUSCHK(d_model_step(m, t, dt));
+      t += dt;
+      ++step;
+    }
+  }
+  HIPCHK(hipStreamSynchronize(m->ctx->stream));
+  if (nsteps)
+    *nsteps = step;
+  return FUS_OK;
+}
+
+int fus_model_rk4_steps(fus_model* m, double t0, double dt, int64_t nsteps)
+{
+  if (!m)
+    return fail(FUS_ERR_ARG, "null model");
+  if (!m->initialised)
+    return fail(FUS_ERR_STATE, "fus_model_init (or fus_model_set) must be called before rk4");
+  HIPCHK(hipSetDevice(m->ctx->device));
+  double t = t0;
+  for (int64_t s = 0; s < nsteps; ++s)
+  {
+    FUSCHK(d_model_step(m, t, dt));
+    t += dt;
+  }
+  return FUS_OK;
+}
+
+int fus_model_get(fus_model* m, int which, void* out, int space)
+{
+  if (!m || !out || (which != FUS_U && which != FUS_V))
+    return fail(FUS_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(m->ctx->device));
+  return m->op->dtype == FUS_F64 ? model_getset<double>(m, which, out, space, false)
+                                 : model_getset<float>(m, which, out, space, false);
+}
+
+int fus_model_set(fus_model* m, int which, const void* in, int space)
+{
+  if (!m || !in || (which != FUS_U && which != FUS_V))
+    return fail(FUS_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(m->ctx->device));
+  m->initialised = true;
+  return m->op->dtype == FUS_F64
+             ? model_getset<double>(m, which, const_cast<void*>(in), space, true)
+             : model_getset<float>(m, which, const_cast<void*>(in), space, true);
+}
+
+int fus_model_get_mass(fus_model* m, void* out)
+{
+  if (!m || !out)
+    return fail(FUS_ERR_ARG, "null argument");
+  HIPCHK(hipSetDevice(m->ctx->device));
+  fus_op* op = m->op;
+  hipStream_t st = m->ctx->stream;
+  if (op->dtype == FUS_F64)
+    hipLaunchKernelGGL((k_from_internal<double, 0>), dim3(nblk(op->ndofs)), dim3(256), 0, st,
+                       op->ndofs, op->d_dof_perm, static_cast<const double*>(m->m),
+                       static_cast<double*>(op->d_tmp_c));
+  else
+    hipLaunchKernelGGL((k_from_internal<float, 0>), dim3(nblk(op->ndofs)), dim3(256), 0, st,
+                       op->ndofs, op->d_dof_perm, static_cast<const float*>(m->m),
+                       static_cast<float*>(op->d_tmp_c));
+  HIPCHK(hipMemcpyAsync(out, op->d_tmp_c, op->ndofs * op->ts, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return FUS_OK;
+}
+
+int64_t fus_model_ndofs(fus_model* m) { return m ? m->op->ndofs : 0; }
+
+int fus_profile_enable(fus_ctx* c, int on)
+{
+  if (!c)
+    return fail(FUS_ERR_ARG, "null ctx");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  for (auto& kv : c->profs)
+    for (auto& ev : kv.second.ev)
+      (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
+  c->profs.clear();
+  c->prof = on != 0;
+  return FUS_OK;
+}
+
+int fus_profile_get(fus_ctx* c, const char* name, double* total_ms, int64_t* count)
+{
+  if (!c || !name)
+    return fail(FUS_ERR_ARG, "null argument");
+  HIPCHK(hipStreamSynchronize(c->stream));
+  auto it = c->profs.find(name);
+  double ms = 0;
+  int64_t n = 0;
+  if (it != c->profs.end())
+  {
+    Prof& p = it->second;
+    for (auto& ev : p.ev)
+    {
+      float f = 0;
+      HIPCHK(hipEventElapsedTime(&f, ev.first, ev.second));
+      p.done_ms += f, p.done_count += 1;
+      (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
+    }
+    p.ev.clear();
+    ms = p.done_ms, n = p.done_count;
+  }
+  if (total_ms)
+    *total_ms = ms;
+  if (count)
+    *count = n;
+  return FUS_OK;
+}
+
+} // extern "C"

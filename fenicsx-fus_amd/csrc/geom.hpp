@@ -1,0 +1,67 @@
+// geom.hpp -- trilinear hexahedron geometry shared by the device setup kernel and the host
+// boundary-weight builder.  Restates, for degree-1 geometry, what the reference obtains from
+// DOLFINx's CoordinateElement in compute_scaled_geometrical_factor /
+// compute_scaled_jacobian_determinant (cpp/fenicsx-sf/common/precompute.hpp:101-213, 33-94):
+// J_ij = sum_v x_v,i dphi_v/dX_j,  K = J^-1,  G = K K^T |det J| w,  detJw = |det J| w.
+#pragma once
+
+#if defined(__HIPCC__)
+#define FUS_HD __host__ __device__
+#else
+#define FUS_HD
+#endif
+
+namespace fus
+{
+
+// cd[v][i]: coordinates of vertex v = vx + 2 vy + 4 vz.  X: reference point in [0,1]^3.
+template <typename T>
+FUS_HD inline void jacobian3(const T cd[8][3], double X0, double X1, double X2, T J[3][3])
+{
+  const double X[3] = {X0, X1, X2};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      J[i][j] = 0;
+  for (int v = 0; v < 8; ++v)
+  {
+    T f[3], df[3];
+    for (int d = 0; d < 3; ++d)
+    {
+      const int bit = (v >> d) & 1;
+      f[d] = (T)(bit ? X[d] : 1.0 - X[d]);
+      df[d] = (T)(bit ? 1.0 : -1.0);
+    }
+    const T g[3] = {df[0] * f[1] * f[2], f[0] * df[1] * f[2], f[0] * f[1] * df[2]};
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 3; ++j)
+        J[i][j] += cd[v][i] * g[j];
+  }
+}
+
+// G6 = (xx, xy, xz, yy, yz, zz) of K K^T |det J| w; returns |det J| w  (precompute.hpp:191-208)
+template <typename T>
+FUS_HD inline T geometric_factor3(const T J[3][3], T w, T G6[6])
+{
+  const T c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+  const T c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+  const T c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+  const T det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+  T K[3][3];
+  K[0][0] = c00 / det;
+  K[1][0] = c01 / det;
+  K[2][0] = c02 / det;
+  K[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+  K[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+  K[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+  K[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+  K[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+  K[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+  const T dw = (det < 0 ? -det : det) * w;
+  int n = 0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = i; j < 3; ++j)
+      G6[n++] = dw * (K[i][0] * K[j][0] + K[i][1] * K[j][1] + K[i][2] * K[j][2]);
+  return dw;
+}
+
+} // namespace fus

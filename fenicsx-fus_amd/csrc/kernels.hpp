@@ -1,0 +1,468 @@
+// kernels.hpp -- CDNA4 (gfx950) device code of libfusmi.  Included by fusmi.hip only.
+//
+// Hot kernels
+//   k_block_op<T,P,OP>   the sum-factorised operator action on one LDS block of elements
+//                        (reference: StiffnessSpectral3D / MassSpectral3D ::operator(),
+//                        cpp/fenicsx-sf/common/spectral_op.hpp:173-243, 69-86)
+//   k_shared_reduce<T>   fixed-order sum of per-block partials of shared DOFs
+//                        (replaces the `+=` scatter of spectral_op.hpp:240-241 across blocks)
+//   k_stage<T,STAGE>     fused RK4 stage update (reference: 9 separate vector passes per stage,
+//                        Linear.hpp:274-294 + :212-221)
+//
+// Thread mapping of k_block_op (wave = 64 lanes): lane p = (b, c) of the N x N plane
+// (tensor indices 1 and 2), registers run along tensor index 0; EPW = 64 / N^2 elements per wave
+// (N=5: two elements, 50 live lanes).  Index-0 contractions are pure register FMAs against the
+// derivative table held in SGPRs (kernel argument); index-1/2 contractions exchange through a
+// per-element LDS tile.  Geometry factors stream from HBM with 16-byte loads in a per-lane
+// vector layout; nothing is read twice.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "geom.hpp"
+
+namespace fus
+{
+
+struct ShapeDev
+{
+  int32_t nelem, nloc, nint, nrounds;
+  int64_t rounds_off, ldm_off;
+};
+
+struct BlockArgs
+{
+  const int32_t* blk_shape;
+  const ShapeDev* shapes;
+  const int32_t* blk_elem_off;
+  const int32_t* blk_int_off;
+  const int64_t* blk_sh_off;
+  const int32_t* sh_gidx;
+  const int16_t* rounds;
+  const uint16_t* ldm;
+  int32_t nblocks;
+  int32_t lds_nloc;  // LDS array length (>= max nloc, even)
+  int32_t waves;
+};
+
+template <typename T, int N>
+struct DTab
+{
+  T d[N * N];
+};
+
+// values per 16-byte (or 8-byte) geometry load
+template <typename T, int N>
+struct GLoad
+{
+  static constexpr int VW = (sizeof(T) == 8) ? 2 : (((6 * N) % 4 == 0) ? 4 : 2);
+  static constexpr int NV = 6 * N / VW;
+  typedef T type __attribute__((ext_vector_type(VW)));
+};
+
+// position of geometry value v = g*N + a of lane p inside an element's 6*Nd block
+template <typename T, int N>
+__host__ __device__ inline int64_t g_index(int v, int p)
+{
+  constexpr int VW = GLoad<T, N>::VW;
+  return (int64_t)((v / VW) * (N * N) + p) * VW + (v % VW);
+}
+
+#define FUS_WAVE_SYNC()                                                                            \
+  do                                                                                               \
+  {                                                                                                \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                                         \
+    __builtin_amdgcn_wave_barrier();                                                               \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");                                         \
+  } while (0)
+
+enum
+{
+  OP_STIFFNESS = 0,
+  OP_MASS = 1
+};
+
+// ---------------------------------------------------------------------------------------------
+// Block operator:  bvec[interior dofs of block] = (A x)[...],  partial[(block, shared slot)] =
+// this block's contribution to a shared dof.  x, bvec in internal numbering.
+// geo = G (6*Nd per element, per-lane vector layout) for OP_STIFFNESS, detJw (Nd per element,
+// tensor order) for OP_MASS.  coef: one scalar per internal element.
+template <typename T, int P, int OP>
+__global__ void __launch_bounds__(256)
+k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
+           const T* __restrict__ geo, const T* __restrict__ coef, const T* __restrict__ x,
+           T* __restrict__ bvec, T* __restrict__ partial)
+{
+  constexpr int N = P + 1, N2 = N * N, Nd = N * N * N;
+  constexpr int EPW = (64 / N2) > 0 ? (64 / N2) : 1;
+  typedef typename GLoad<T, N>::type GV;
+  constexpr int VW = GLoad<T, N>::VW, NV = GLoad<T, N>::NV;
+
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  T* x_l = reinterpret_cast<T*>(smem_raw);
+  T* y_l = x_l + A.lds_nloc;
+  T* scratch = y_l + A.lds_nloc;
+
+  const int blk = blockIdx.x;
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  const ShapeDev sh = A.shapes[A.blk_shape[blk]];
+  const int elem_off = A.blk_elem_off[blk];
+  const int int_off = A.blk_int_off[blk];
+  const int64_t sh_off = A.blk_sh_off[blk];
+
+  // ---- prologue: stage the block's dof values in LDS, clear the accumulator ----
+  for (int l = tid; l < sh.nint; l += nthr)
+  {
+    x_l[l] = x[int_off + l];
+    y_l[l] = T(0);
+  }
+  for (int l = sh.nint + tid; l < sh.nloc; l += nthr)
+  {
+    x_l[l] = x[A.sh_gidx[sh_off + (l - sh.nint)]];
+    y_l[l] = T(0);
+  }
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6;
+  const int s = lane / N2, p = lane - s * N2;
+  const int b = p / N, c = p - b * N;
+  const bool active = s < EPW;
+  const int slots = A.waves * EPW;
+  T* sA = scratch + (size_t)(wave * EPW + (active ? s : 0)) * 2 * Nd;
+  T* sB = sA + Nd;
+
+  // lane-dependent rows/columns of the derivative table (tiny, cache resident)
+  T Drb[N], Drc[N], Dcb[N], Dcc[N];
+  if (OP == OP_STIFFNESS)
+  {
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+    {
+      Drb[j] = Dg[b * N + j];
+      Drc[j] = Dg[c * N + j];
+      Dcb[j] = Dg[j * N + b];
+      Dcc[j] = Dg[j * N + c];
+    }
+  }
+
+  for (int r = 0; r < sh.nrounds; ++r)
+  {
+    const int er = active ? (int)A.rounds[sh.rounds_off + (int64_t)r * slots + wave * EPW + s] : -1;
+    if (er >= 0)
+    {
+      const uint16_t* ldm_e = A.ldm + sh.ldm_off + (int64_t)er * Nd;
+      const int64_t e = elem_off + er;
+      int li[N];
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        li[a] = ldm_e[a * N2 + p];
+      const T cf = coef[e];
+      T Y[N];
+
+      if (OP == OP_STIFFNESS)
+      {
+        // stream this element's geometry factors (issued first, consumed after the forward pass)
+        const T* Ge = geo + e * (6 * Nd);
+        GV g[NV];
+#pragma unroll
+        for (int t = 0; t < NV; ++t)
+          g[t] = *reinterpret_cast<const GV*>(Ge + (size_t)(t * N2 + p) * VW);
+
+        T X[N], F0[N], F1[N], F2[N];
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+          X[a] = x_l[li[a]];
+        // derivative along tensor index 0: registers only (spectral_op.hpp:194-196)
+#pragma unroll
+        for (int q = 0; q < N; ++q)
+        {
+          T acc = T(0);
+#pragma unroll
+          for (int i = 0; i < N; ++i)
+            acc += Dk.d[q * N + i] * X[i];
+          F0[q] = acc;
+        }
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+          sA[a * N2 + p] = X[a];
+        FUS_WAVE_SYNC();
+        // derivatives along tensor indices 1 and 2 (spectral_op.hpp:199-210)
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+        {
+          T f1 = T(0), f2 = T(0);
+#pragma unroll
+          for (int j = 0; j < N; ++j)
+          {
+            f1 += Drb[j] * sA[a * N2 + j * N + c];
+            f2 += Drc[j] * sA[a * N2 + b * N + j];
+          }
+          F1[a] = f1;
+          F2[a] = f2;
+        }
+        // stiffness::transform (spectral_op.hpp:113-130)
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+        {
+          T G6[6];
+#pragma unroll
+          for (int gi = 0; gi < 6; ++gi)
+          {
+            const int v = gi * N + a;
+            G6[gi] = g[v / VW][v % VW];
+          }
+          const T w0 = F0[a], w1 = F1[a], w2 = F2[a];
+          F0[a] = cf * (G6[0] * w0 + G6[1] * w1 + G6[2] * w2);
+          F1[a] = cf * (G6[1] * w0 + G6[3] * w1 + G6[4] * w2);
+          F2[a] = cf * (G6[2] * w0 + G6[4] * w1 + G6[5] * w2);
+        }
+        FUS_WAVE_SYNC();
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+        {
+          sA[a * N2 + p] = F1[a];
+          sB[a * N2 + p] = F2[a];
+        }
+        FUS_WAVE_SYNC();
+        // transposed contractions (spectral_op.hpp:222-238)
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+        {
+          T acc = T(0);
+#pragma unroll
+          for (int q = 0; q < N; ++q)
+            acc += Dk.d[q * N + a] * F0[q];
+#pragma unroll
+          for (int j = 0; j < N; ++j)
+          {
+            acc += Dcb[j] * sA[a * N2 + j * N + c];
+            acc += Dcc[j] * sB[a * N2 + b * N + j];
+          }
+          Y[a] = acc;
+        }
+      }
+      else
+      {
+        // mass::transform (spectral_op.hpp:19-26)
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+          Y[a] = cf * x_l[li[a]] * geo[e * Nd + a * N2 + p];
+      }
+      // scatter-add into the block accumulator (spectral_op.hpp:240-241); elements of one
+      // round share no dof, rounds are ordered -> deterministic
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        y_l[li[a]] += Y[a];
+    }
+    if (A.waves > 1)
+      __syncthreads();
+  }
+  __syncthreads();
+
+  // ---- epilogue: each dof written once ----
+  for (int l = tid; l < sh.nint; l += nthr)
+    bvec[int_off + l] = y_l[l];
+  for (int l = sh.nint + tid; l < sh.nloc; l += nthr)
+    partial[sh_off + (l - sh.nint)] = y_l[l];
+}
+
+// bsh[s] = sum over the (block, slot) pairs of shared dof s, ascending block order
+template <typename T>
+__global__ void k_shared_reduce(int64_t n_shared, const int64_t* __restrict__ sh_ptr,
+                                const int64_t* __restrict__ sh_pairs,
+                                const T* __restrict__ partial, T* __restrict__ bsh)
+{
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n_shared)
+    return;
+  T acc = T(0);
+  for (int64_t k = sh_ptr[s]; k < sh_ptr[s + 1]; ++k)
+    acc += partial[sh_pairs[k]];
+  bsh[s] = acc;
+}
+
+// Diagonal boundary terms (Linear.hpp:205 with forms.py:38-39 collocated at GLL nodes):
+// b[idx] += g(t) * srcw - absw * vn[idx]
+template <typename T>
+__global__ void k_boundary(int64_t nb, const int32_t* __restrict__ idx, const T* __restrict__ srcw,
+                           const T* __restrict__ absw, T gval, const T* __restrict__ vn,
+                           T* __restrict__ b)
+{
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= nb)
+    return;
+  const int32_t i = idx[k];
+  b[i] += gval * srcw[k] - absw[k] * vn[i];
+}
+
+// Fused RK4 stage update.  kv = b * minv  (Linear.hpp:212-221), ku = vn (f0, :171-174).
+//   STAGE 0 : vn == v0, un == u0, u_ == u0, v_ == v0 (aliases are not read twice)
+//             u_ = u0 + bdt*v0 ; v_ = v0 + bdt*kv ; un' = u0 + adt*v0 ; vn' = v0 + adt*kv
+//   STAGE 1,2: u_ += bdt*vn ; v_ += bdt*kv ; un' = u0 + adt*vn ; vn' = v0 + adt*kv
+//   STAGE 3 : u0 = u_ + bdt*vn ; v0 = v_ + bdt*kv        (next step's state, no copies)
+// adt = dt*a_{i+1}, bdt = dt*b_i (Linear.hpp:282-294).
+template <typename T, int STAGE>
+__global__ void __launch_bounds__(256)
+k_stage(int64_t n, const T* __restrict__ b, const T* __restrict__ minv, T* __restrict__ vn,
+        T* __restrict__ un, T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ u_,
+        T* __restrict__ v_, T adt, T bdt)
+{
+  typedef T V __attribute__((ext_vector_type(16 / sizeof(T))));
+  constexpr int VW = 16 / sizeof(T);
+  const int64_t nv = n / VW;  // n is a multiple of 16
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
+       i += (int64_t)gridDim.x * blockDim.x)
+  {
+    const V kv = reinterpret_cast<const V*>(b)[i] * reinterpret_cast<const V*>(minv)[i];
+    if (STAGE == 0)
+    {
+      const V u = reinterpret_cast<const V*>(u0)[i], v = reinterpret_cast<const V*>(v0)[i];
+      reinterpret_cast<V*>(u_)[i] = v * bdt + u;
+      reinterpret_cast<V*>(v_)[i] = kv * bdt + v;
+      reinterpret_cast<V*>(un)[i] = v * adt + u;
+      reinterpret_cast<V*>(vn)[i] = kv * adt + v;
+    }
+    else if (STAGE == 3)
+    {
+      const V w = reinterpret_cast<const V*>(vn)[i];
+      reinterpret_cast<V*>(u0)[i] = w * bdt + reinterpret_cast<const V*>(u_)[i];
+      reinterpret_cast<V*>(v0)[i] = kv * bdt + reinterpret_cast<const V*>(v_)[i];
+    }
+    else
+    {
+      const V w = reinterpret_cast<const V*>(vn)[i];
+      reinterpret_cast<V*>(u_)[i] = w * bdt + reinterpret_cast<const V*>(u_)[i];
+      reinterpret_cast<V*>(v_)[i] = kv * bdt + reinterpret_cast<const V*>(v_)[i];
+      reinterpret_cast<V*>(un)[i] = w * adt + reinterpret_cast<const V*>(u0)[i];
+      reinterpret_cast<V*>(vn)[i] = kv * adt + reinterpret_cast<const V*>(v0)[i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Setup / plumbing kernels
+// ---------------------------------------------------------------------------------------------
+
+// Geometry factors for internal element e at point q (precompute.hpp:101-213, 33-94), written in
+// the operator's streaming layouts.
+template <typename T, int N>
+__global__ void k_geometry(int64_t ncells, const int32_t* __restrict__ cell_perm,
+                           const T* __restrict__ xg, const int32_t* __restrict__ xdofmap,
+                           const double* __restrict__ pts, const double* __restrict__ wts,
+                           T* __restrict__ G, T* __restrict__ detJ)
+{
+  constexpr int N2 = N * N, Nd = N * N * N;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= ncells * Nd)
+    return;
+  const int64_t e = gid / Nd;
+  const int q = (int)(gid - e * Nd);
+  const int a = q / N2, p = q - a * N2, bb = p / N, cc = p - bb * N;
+  const int64_t cell = cell_perm[e];
+  T cd[8][3];
+  for (int v = 0; v < 8; ++v)
+    for (int j = 0; j < 3; ++j)
+      cd[v][j] = xg[3 * (int64_t)xdofmap[cell * 8 + v] + j];
+  T J[3][3], G6[6];
+  jacobian3<T>(cd, pts[a], pts[bb], pts[cc], J);
+  const T w = (T)(wts[a] * wts[bb] * wts[cc]);
+  const T dw = geometric_factor3<T>(J, w, G6);
+  detJ[e * Nd + q] = dw;
+  for (int gi = 0; gi < 6; ++gi)
+    G[e * (6 * Nd) + g_index<T, N>(gi * N + a, p)] = G6[gi];
+}
+
+// internal streaming layout -> reference layout G[cell][point][6], detJ[cell][point]
+template <typename T, int N>
+__global__ void k_geometry_export(int64_t ncells, const int32_t* __restrict__ cell_perm,
+                                  const T* __restrict__ G, const T* __restrict__ detJ,
+                                  T* __restrict__ Gout, T* __restrict__ dout)
+{
+  constexpr int N2 = N * N, Nd = N * N * N;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= ncells * Nd)
+    return;
+  const int64_t e = gid / Nd;
+  const int q = (int)(gid - e * Nd);
+  const int a = q / N2, p = q - a * N2;
+  const int64_t cell = cell_perm[e];
+  if (dout)
+    dout[cell * Nd + q] = detJ[e * Nd + q];
+  if (Gout)
+    for (int gi = 0; gi < 6; ++gi)
+      Gout[(cell * Nd + q) * 6 + gi] = G[e * (6 * Nd) + g_index<T, N>(gi * N + a, p)];
+}
+
+// out_internal[perm[i]] = in_caller[i]
+template <typename T>
+__global__ void k_to_internal(int64_t n, const int32_t* __restrict__ perm, const T* __restrict__ in,
+                              T* __restrict__ out)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[perm[i]] = in[i];
+}
+
+// y_caller[i] = (ACC ? y_caller[i] : 0) + in_internal[perm[i]]
+template <typename T, int ACC>
+__global__ void k_from_internal(int64_t n, const int32_t* __restrict__ perm,
+                                const T* __restrict__ in, T* __restrict__ y)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    y[i] = (ACC ? y[i] : T(0)) + in[perm[i]];
+}
+
+// out[e] = in[cell_perm[e]]
+template <typename T>
+__global__ void k_cells_to_internal(int64_t n, const int32_t* __restrict__ cell_perm,
+                                    const T* __restrict__ in, T* __restrict__ out)
+{
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n)
+    out[e] = in[cell_perm[e]];
+}
+
+template <typename T>
+__global__ void k_fill(int64_t n, T* __restrict__ x, T v)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    x[i] = v;
+}
+
+// minv = 1/m where m != 0 (padding slots stay 0)
+template <typename T>
+__global__ void k_reciprocal(int64_t n, const T* __restrict__ m, T* __restrict__ minv)
+{
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    minv[i] = (m[i] != T(0)) ? T(1) / m[i] : T(0);
+}
+
+// halo helpers:  buf[k] = vec[idx[k]] ;  vec[idx[k]] = 0 ;  vec[idx[k]] += buf[k]
+template <typename T>
+__global__ void k_pack(int64_t n, const int32_t* __restrict__ idx, const T* __restrict__ vec,
+                       T* __restrict__ buf)
+{
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n)
+    buf[k] = vec[idx[k]];
+}
+template <typename T>
+__global__ void k_zero_at(int64_t n, const int32_t* __restrict__ idx, T* __restrict__ vec)
+{
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n)
+    vec[idx[k]] = T(0);
+}
+template <typename T>
+__global__ void k_add_at(int64_t n, const int32_t* __restrict__ idx, const T* __restrict__ buf,
+                         T* __restrict__ vec)
+{
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < n)
+    vec[idx[k]] += buf[k];
+}
+
+} // namespace fus

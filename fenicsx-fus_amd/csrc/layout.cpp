@@ -1,0 +1,372 @@
+// layout.cpp -- block partition, conflict-free rounds and internal DOF numbering (host only).
+// See layout.hpp.  Replaces the role of the reference's serial cell order + global scatter-add
+// (cpp/fenicsx-sf/common/spectral_op.hpp:183-242) with a structure the GPU can execute without
+// atomics.
+#include "layout.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <numeric>
+
+namespace fus
+{
+namespace
+{
+struct Rcb
+{
+  const double* cen;
+  std::vector<int32_t>& order;
+  std::vector<std::pair<int64_t, int64_t>>& leaves;
+
+  void split(int64_t lo, int64_t hi, int64_t nparts)
+  {
+    if (nparts <= 1 || hi - lo <= 1)
+    {
+      leaves.emplace_back(lo, hi);
+      return;
+    }
+    double mn[3] = {1e300, 1e300, 1e300}, mx[3] = {-1e300, -1e300, -1e300};
+    for (int64_t k = lo; k < hi; ++k)
+      for (int d = 0; d < 3; ++d)
+      {
+        const double v = cen[3 * (int64_t)order[k] + d];
+        mn[d] = std::min(mn[d], v);
+        mx[d] = std::max(mx[d], v);
+      }
+    int ax = 0;
+    for (int d = 1; d < 3; ++d)
+      if (mx[d] - mn[d] > (mx[ax] - mn[ax]) * (1.0 + 1e-9))
+        ax = d;
+    const int64_t nl = nparts / 2;
+    const int64_t mid = lo + ((hi - lo) * nl) / nparts;
+    const double* c = cen;
+    std::nth_element(order.begin() + lo, order.begin() + mid, order.begin() + hi,
+                     [c, ax](int32_t a, int32_t b)
+                     {
+                       const double va = c[3 * (int64_t)a + ax], vb = c[3 * (int64_t)b + ax];
+                       return va < vb || (va == vb && a < b);
+                     });
+    split(lo, mid, nl);
+    split(mid, hi, nparts - nl);
+  }
+};
+} // namespace
+
+std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
+                         const int32_t* dm, const double* centroids, int block_elems, int waves)
+{
+  if (P < 1 || P > 15)
+    return "unsupported degree";
+  if (ncells <= 0 || ndofs <= 0)
+    return "empty mesh";
+  L = Layout();
+  L.P = P, L.N = P + 1, L.Nd = L.N * L.N * L.N;
+  L.ncells = ncells, L.ndofs = ndofs;
+  L.waves = std::max(1, waves);
+  L.epw = std::max(1, 64 / (L.N * L.N));
+  L.slots = L.waves * L.epw;
+  const int Nd = L.Nd;
+  if (block_elems < 1)
+    block_elems = 64;
+
+  // ---- 1. recursive coordinate bisection into compact blocks ----
+  std::vector<int32_t> order(ncells);
+  std::iota(order.begin(), order.end(), 0);
+  std::vector<std::pair<int64_t, int64_t>> leaves;
+  const int64_t nparts = (ncells + block_elems - 1) / block_elems;
+  Rcb{centroids, order, leaves}.split(0, ncells, nparts);
+  L.nblocks = (int32_t)leaves.size();
+  for (auto& lf : leaves)
+    std::sort(order.begin() + lf.first, order.begin() + lf.second);
+
+  // ---- 2. how many blocks touch each dof ----
+  std::vector<int32_t> last_blk(ndofs, -1);
+  std::vector<uint8_t> nblk(ndofs, 0);
+  for (int32_t b = 0; b < L.nblocks; ++b)
+    for (int64_t k = leaves[b].first; k < leaves[b].second; ++k)
+    {
+      const int32_t* d = dm + (int64_t)order[k] * Nd;
+      for (int i = 0; i < Nd; ++i)
+      {
+        if (d[i] < 0 || d[i] >= ndofs)
+          return "dofmap entry out of range";
+        if (last_blk[d[i]] != b)
+        {
+          last_blk[d[i]] = b;
+          if (nblk[d[i]] < 255)
+            ++nblk[d[i]];
+        }
+      }
+    }
+
+  // ---- 3. per block: rounds, local numbering, internal numbering ----
+  L.cell_perm.resize(ncells);
+  L.blk_elem_off.assign(L.nblocks + 1, 0);
+  L.blk_shape.resize(L.nblocks);
+  L.blk_int_off.resize(L.nblocks);
+  L.blk_sh_off.assign(L.nblocks + 1, 0);
+  L.dof_perm.assign(ndofs, -1);
+  std::vector<int32_t> sh_id(ndofs, -1);          // shared dof -> shared index
+  std::vector<int32_t> loc_of(ndofs, -1), loc_blk(ndofs, -1);
+  std::vector<int32_t> pair_shid;                 // [npairs] shared index of each pair
+  std::map<std::vector<uint16_t>, int32_t> shape_map;
+  int64_t int_cursor = 0;
+  std::vector<uint64_t> rmask;
+  std::vector<uint16_t> key;
+
+  for (int32_t b = 0; b < L.nblocks; ++b)
+  {
+    const int64_t lo = leaves[b].first, hi = leaves[b].second;
+    const int32_t nelem = (int32_t)(hi - lo);
+    L.blk_elem_off[b + 1] = L.blk_elem_off[b] + nelem;
+    if (nelem > 32767)
+      return "block too large";
+
+    // temporary local ids (first appearance) for the conflict masks
+    int32_t ntmp = 0;
+    for (int64_t k = lo; k < hi; ++k)
+    {
+      const int32_t* d = dm + (int64_t)order[k] * Nd;
+      for (int i = 0; i < Nd; ++i)
+        if (loc_blk[d[i]] != b)
+          loc_blk[d[i]] = b, loc_of[d[i]] = ntmp++;
+    }
+    if (ntmp > 65535)
+      return "block has more than 65535 local dofs";
+    rmask.assign(ntmp, 0);
+    // greedy first-fit: an element goes to the first round where it shares no dof with the
+    // round's other elements and a slot is free
+    std::vector<std::vector<int32_t>> rd;  // rd[r] = positions (k - lo)
+    for (int64_t k = lo; k < hi; ++k)
+    {
+      const int32_t* d = dm + (int64_t)order[k] * Nd;
+      uint64_t busy = 0;
+      for (int i = 0; i < Nd; ++i)
+        busy |= rmask[loc_of[d[i]]];
+      int r = 0;
+      for (;; ++r)
+      {
+        if (r >= 64)
+          return "block needs more than 64 rounds";
+        if (busy & (1ull << r))
+          continue;
+        if (r < (int)rd.size() && (int)rd[r].size() >= L.slots)
+          continue;
+        break;
+      }
+      if (r >= (int)rd.size())
+        rd.resize(r + 1);
+      rd[r].push_back((int32_t)(k - lo));
+      for (int i = 0; i < Nd; ++i)
+        rmask[loc_of[d[i]]] |= (1ull << r);
+    }
+    const int32_t nrounds = (int32_t)rd.size();
+
+    // internal element order = (round, slot), compact
+    std::vector<int16_t> rtab((size_t)nrounds * L.slots, (int16_t)-1);
+    std::vector<int32_t> erel_cell(nelem);
+    int32_t er = 0;
+    for (int r = 0; r < nrounds; ++r)
+      for (size_t s = 0; s < rd[r].size(); ++s)
+      {
+        rtab[(size_t)r * L.slots + s] = (int16_t)er;
+        erel_cell[er] = order[lo + rd[r][s]];
+        L.cell_perm[L.blk_elem_off[b] + er] = erel_cell[er];
+        ++er;
+      }
+
+    // final local numbering: interior dofs first, then shared, each by first appearance
+    int32_t nint = 0, nsh = 0;
+    for (int pass = 0; pass < 2; ++pass)
+    {
+      for (int32_t e = 0; e < nelem; ++e)
+      {
+        const int32_t* d = dm + (int64_t)erel_cell[e] * Nd;
+        for (int i = 0; i < Nd; ++i)
+        {
+          const int32_t g = d[i];
+          const bool shared = nblk[g] > 1;
+          if (pass == 0)
+          {
+            if (!shared && loc_blk[g] == b)
+              loc_blk[g] = -2 - b, loc_of[g] = nint++;   // mark assigned
+          }
+          else if (shared && loc_blk[g] == b)
+            loc_blk[g] = -2 - b, loc_of[g] = nint + nsh++;
+        }
+      }
+    }
+    const int32_t nloc = nint + nsh;
+    L.max_nloc = std::max(L.max_nloc, nloc);
+
+    // internal numbering
+    int_cursor = (int_cursor + 15) & ~(int64_t)15;
+    if (int_cursor + nint > 2000000000ll)
+      return "local vector exceeds int32 indexing";
+    L.blk_int_off[b] = (int32_t)int_cursor;
+    L.blk_sh_off[b + 1] = L.blk_sh_off[b] + nsh;
+    L.sh_gidx.resize(L.blk_sh_off[b + 1]);
+    pair_shid.resize(L.blk_sh_off[b + 1]);
+
+    key.clear();
+    key.push_back((uint16_t)nelem), key.push_back((uint16_t)nloc);
+    key.push_back((uint16_t)nint), key.push_back((uint16_t)nrounds);
+    for (auto v : rtab)
+      key.push_back((uint16_t)v);
+    const size_t ldm_start = key.size();
+    key.resize(ldm_start + (size_t)nelem * Nd);
+    for (int32_t e = 0; e < nelem; ++e)
+    {
+      const int32_t* d = dm + (int64_t)erel_cell[e] * Nd;
+      for (int i = 0; i < Nd; ++i)
+      {
+        const int32_t g = d[i];
+        const int32_t l = loc_of[g];
+        key[ldm_start + (size_t)e * Nd + i] = (uint16_t)l;
+        if (l < nint)
+          L.dof_perm[g] = (int32_t)(int_cursor + l);
+        else
+        {
+          if (sh_id[g] < 0)
+            sh_id[g] = (int32_t)L.n_shared++;
+          pair_shid[L.blk_sh_off[b] + (l - nint)] = sh_id[g];
+        }
+      }
+    }
+    int_cursor += nint;
+    L.n_interior += nint;
+
+    auto it = shape_map.find(key);
+    if (it == shape_map.end())
+    {
+      Layout::Shape sh;
+      sh.nelem = nelem, sh.nloc = nloc, sh.nint = nint, sh.nrounds = nrounds;
+      sh.rounds_off = (int64_t)L.rounds.size();
+      L.rounds.insert(L.rounds.end(), rtab.begin(), rtab.end());
+      sh.ldm_off = (int64_t)L.ldm.size();
+      L.ldm.insert(L.ldm.end(), key.begin() + ldm_start, key.end());
+      const int32_t id = (int32_t)L.shapes.size();
+      L.shapes.push_back(sh);
+      it = shape_map.emplace(key, id).first;
+    }
+    L.blk_shape[b] = it->second;
+  }
+
+  // dofs no cell touches (none in a consistent mesh) still need a slot
+  for (int64_t g = 0; g < ndofs; ++g)
+    if (nblk[g] == 0)
+      sh_id[g] = (int32_t)L.n_shared++;
+
+  L.n_int_pad = (int_cursor + 15) & ~(int64_t)15;
+  L.npairs = L.blk_sh_off[L.nblocks];
+  L.n_internal = (L.n_int_pad + L.n_shared + 15) & ~(int64_t)15;
+  if (L.n_internal > 2000000000ll)
+    return "local vector exceeds int32 indexing";
+  for (int64_t g = 0; g < ndofs; ++g)
+    if (sh_id[g] >= 0)
+      L.dof_perm[g] = (int32_t)(L.n_int_pad + sh_id[g]);
+  for (int64_t k = 0; k < L.npairs; ++k)
+    L.sh_gidx[k] = (int32_t)(L.n_int_pad + pair_shid[k]);
+
+  // shared dof -> pairs CSR, ascending pair (= block) order
+  L.sh_ptr.assign(L.n_shared + 1, 0);
+  for (int64_t k = 0; k < L.npairs; ++k)
+    ++L.sh_ptr[pair_shid[k] + 1];
+  for (int64_t s = 0; s < L.n_shared; ++s)
+    L.sh_ptr[s + 1] += L.sh_ptr[s];
+  L.sh_pairs.resize(L.npairs);
+  {
+    std::vector<int64_t> cur(L.sh_ptr.begin(), L.sh_ptr.end() - 1);
+    for (int64_t k = 0; k < L.npairs; ++k)
+      L.sh_pairs[cur[pair_shid[k]]++] = k;
+  }
+  return "";
+}
+
+std::string verify_layout(const Layout& L, const int32_t* dm)
+{
+  const int Nd = L.Nd;
+  // cell_perm is a permutation
+  {
+    std::vector<uint8_t> seen(L.ncells, 0);
+    for (int64_t e = 0; e < L.ncells; ++e)
+    {
+      const int32_t c = L.cell_perm[e];
+      if (c < 0 || c >= L.ncells || seen[c])
+        return "cell_perm is not a permutation";
+      seen[c] = 1;
+    }
+  }
+  // dof_perm is injective into [0, n_internal)
+  {
+    std::vector<uint8_t> seen(L.n_internal, 0);
+    for (int64_t g = 0; g < L.ndofs; ++g)
+    {
+      const int32_t p = L.dof_perm[g];
+      if (p < 0 || p >= L.n_internal || seen[p])
+        return "dof_perm is not injective";
+      seen[p] = 1;
+    }
+  }
+  int64_t pairs_seen = 0;
+  for (int32_t b = 0; b < L.nblocks; ++b)
+  {
+    const Layout::Shape& sh = L.shapes[L.blk_shape[b]];
+    if (sh.nelem != L.blk_elem_off[b + 1] - L.blk_elem_off[b])
+      return "shape/element count mismatch";
+    if (sh.nloc - sh.nint != L.blk_sh_off[b + 1] - L.blk_sh_off[b])
+      return "shape/shared count mismatch";
+    if (L.blk_int_off[b] % 16)
+      return "interior range not 128-byte aligned";
+    // local dofmap maps back to the caller dofmap through the internal numbering
+    for (int32_t e = 0; e < sh.nelem; ++e)
+    {
+      const int32_t* d = dm + (int64_t)L.cell_perm[L.blk_elem_off[b] + e] * Nd;
+      for (int i = 0; i < Nd; ++i)
+      {
+        const int32_t l = L.ldm[sh.ldm_off + (int64_t)e * Nd + i];
+        if (l >= sh.nloc)
+          return "local index out of range";
+        const int32_t internal = l < sh.nint ? L.blk_int_off[b] + l
+                                             : L.sh_gidx[L.blk_sh_off[b] + (l - sh.nint)];
+        if (internal != L.dof_perm[d[i]])
+          return "local dofmap inconsistent with dof_perm";
+      }
+    }
+    // rounds: every element exactly once, no dof shared inside a round
+    std::vector<int> used(sh.nelem, 0);
+    std::vector<int32_t> stamp(sh.nloc, -1);
+    for (int32_t r = 0; r < sh.nrounds; ++r)
+      for (int s = 0; s < L.slots; ++s)
+      {
+        const int e = L.rounds[sh.rounds_off + (int64_t)r * L.slots + s];
+        if (e < 0)
+          continue;
+        if (e >= sh.nelem || used[e]++)
+          return "round table does not cover each element once";
+        for (int i = 0; i < Nd; ++i)
+          if (stamp[L.ldm[sh.ldm_off + (int64_t)e * Nd + i]] == r)
+            return "two elements of one round share a dof";
+        for (int i = 0; i < Nd; ++i)
+          stamp[L.ldm[sh.ldm_off + (int64_t)e * Nd + i]] = r;
+      }
+    for (int e = 0; e < sh.nelem; ++e)
+      if (!used[e])
+        return "element missing from rounds";
+    pairs_seen += sh.nloc - sh.nint;
+  }
+  if (pairs_seen != L.npairs)
+    return "pair count mismatch";
+  for (int64_t s = 0; s < L.n_shared; ++s)
+    for (int64_t k = L.sh_ptr[s]; k < L.sh_ptr[s + 1]; ++k)
+    {
+      if (L.sh_gidx[L.sh_pairs[k]] != L.n_int_pad + s)
+        return "shared CSR inconsistent";
+      if (k > L.sh_ptr[s] && L.sh_pairs[k] <= L.sh_pairs[k - 1])
+        return "shared CSR not in ascending block order";
+    }
+  return "";
+}
+
+} // namespace fus

@@ -1,0 +1,118 @@
+"""ctypes binding of libfusmi's C ABI (include/fusmi.h).  Fails loudly when the HIP extension is
+missing or no device is present -- there is no CPU path behind these calls."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfusmi.so")
+
+FUS_F32, FUS_F64 = 0, 1
+FUS_HOST, FUS_DEVICE = 0, 1
+FUS_LINEAR, FUS_LOSSY, FUS_WESTERVELT = 0, 1, 2
+FUS_U, FUS_V = 0, 1
+
+# every symbol include/fusmi.h declares
+SYMBOLS = [
+    "fus_last_error", "fus_version", "fus_init", "fus_finalize", "fus_synchronize", "fus_set_option",
+    "fus_comm_unique_id", "fus_comm_init", "fus_op_create", "fus_op_destroy", "fus_stiffness_apply",
+    "fus_mass_apply", "fus_op_get_geometry", "fus_op_get_tables", "fus_op_info", "fus_facet_diag",
+    "fus_op_set_neighbours", "fus_model_create", "fus_model_destroy", "fus_model_init", "fus_model_rk4",
+    "fus_model_rk4_steps", "fus_model_get", "fus_model_set", "fus_model_get_mass", "fus_model_ndofs",
+    "fus_profile_enable", "fus_profile_get", "fus_layout_check",
+]
+
+
+class FusError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FusError(
+                f"{LIB_PATH} not found: build the HIP extension first (python fenicsx-fus_amd/build.py)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.fus_last_error.restype = C.c_char_p
+        _lib.fus_model_ndofs.restype = C.c_int64
+    return _lib
+
+
+def check(code: int) -> None:
+    if code != 0:
+        raise FusError(f"libfusmi error {code}: {lib().fus_last_error().decode()}")
+
+
+def ptr(a):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def dtype_code(dt) -> int:
+    dt = np.dtype(dt)
+    if dt == np.float64:
+        return FUS_F64
+    if dt == np.float32:
+        return FUS_F32
+    raise FusError(f"unsupported scalar type {dt}")
+
+
+class Context:
+    """One per GPU (fus_init)."""
+
+    def __init__(self, device: int = 0, block_elems: int | None = None, waves: int | None = None):
+        self.h = C.c_void_p()
+        check(lib().fus_init(C.c_int(device), C.byref(self.h)))
+        if block_elems is not None:
+            self.set_option("block_elems", block_elems)
+        if waves is not None:
+            self.set_option("waves", waves)
+        self.rank, self.nranks = 0, 1
+
+    def set_option(self, key: str, value: int):
+        check(lib().fus_set_option(self.h, key.encode(), C.c_int64(value)))
+
+    def synchronize(self):
+        check(lib().fus_synchronize(self.h))
+
+    def comm_init(self, rank: int, nranks: int, unique_id: bytes | None):
+        buf = (C.c_char * 128).from_buffer_copy(unique_id) if unique_id else None
+        check(lib().fus_comm_init(self.h, C.c_int(rank), C.c_int(nranks), buf))
+        self.rank, self.nranks = rank, nranks
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_char * 128)()
+        check(lib().fus_comm_unique_id(buf))
+        return bytes(buf)
+
+    def profile_enable(self, on: bool = True):
+        check(lib().fus_profile_enable(self.h, C.c_int(int(on))))
+
+    def profile_get(self, name: str):
+        ms, n = C.c_double(), C.c_int64()
+        check(lib().fus_profile_get(self.h, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self.h:
+            lib().fus_finalize(self.h)
+            self.h = C.c_void_p()
+
+
+def layout_check(P, tensor_dofmap, centroids, block_elems=64, waves=4):
+    """Host-only: run the block partitioner + verifier; returns the 8 statistics of fus_op_info."""
+    dm = np.ascontiguousarray(tensor_dofmap, dtype=np.int32)
+    cen = np.ascontiguousarray(centroids, dtype=np.float64)
+    out = (C.c_int64 * 8)()
+    check(lib().fus_layout_check(C.c_int(P), C.c_int64(dm.shape[0]), C.c_int64(int(dm.max()) + 1), ptr(dm),
+                                 ptr(cen), C.c_int(block_elems), C.c_int(waves), out))
+    return list(out)

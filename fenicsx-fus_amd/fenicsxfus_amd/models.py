@@ -1,0 +1,99 @@
+"""Host-side mirror of the reference model classes for the offloaded path.
+
+``LinearSpectralExplicit`` keeps the constructor and ``init()`` / ``rk(t0, tf)`` signatures of
+python/src/fenicsxfus/_linear.py:258-513 (and is the Python face of the C++ ``LinearSpectral3D``,
+cpp/fenicsx-sf/common/Linear.hpp:52-347).  The whole RK4 loop runs on the GPU through
+``fus_model_rk4``; only the classical 4th-order scheme (``rk_order == 4``) is offloaded.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _abi
+from ._abi import Context, check, lib, ptr
+from .mesh import Function, FunctionSpace
+from .operators import SpectralOperatorData, _array
+
+
+class LinearSpectralExplicit:
+    """``LinearSpectralExplicit(mesh, meshtags, k, c0, rho0, freq0, p0, s0, rk_order, dt)``
+    (_linear.py:267).  ``meshtags`` carries boundary facets as (cell, local facet) pairs with
+    ``values`` 1 = source, 2 = absorbing (what ``compute_integration_domains`` yields for the
+    tagged facets, Linear.hpp:113-118)."""
+
+    def __init__(self, mesh, meshtags, k, c0, rho0, freq0, p0, s0, rk_order=4, dt=None, V=None,
+                 ctx: Context | None = None):
+        if rk_order != 4:
+            raise _abi.FusError("only the classical RK4 scheme (rk_order=4) is offloaded")
+        self.mesh, self.dt = mesh, dt
+        self.freq, self.p0, self.s0 = float(freq0), float(p0), float(s0)
+        self.V = V or FunctionSpace(mesh, k)
+        self.data = SpectralOperatorData(self.V, ctx)
+        self.ctx = self.data.ctx
+        dt_ = self.data.dtype
+        c0a = np.ascontiguousarray(_array(c0), dtype=dt_)
+        rhoa = np.ascontiguousarray(_array(rho0), dtype=dt_)
+        cells = np.ascontiguousarray(meshtags.cells, dtype=np.int32)
+        lf = np.ascontiguousarray(meshtags.local_facets, dtype=np.int32)
+        tags = np.ascontiguousarray(meshtags.values, dtype=np.int32)
+        self.h = C.c_void_p()
+        check(lib().fus_model_create(self.ctx.h, C.c_int(_abi.FUS_LINEAR), self.data.h, ptr(c0a), ptr(rhoa),
+                                     None, None, C.c_int64(len(cells)), ptr(cells), ptr(lf), ptr(tags),
+                                     C.c_double(self.freq), C.c_double(self.p0), C.c_double(self.s0),
+                                     C.byref(self.h)))
+        self.u_n = Function(self.V, dt_)
+        self.v_n = Function(self.V, dt_)
+
+    def init(self):
+        """u_n = v_n = 0 (_linear.py:363-369, Linear.hpp:161-164)."""
+        self.u_n.x.array[:] = 0.0
+        self.v_n.x.array[:] = 0.0
+        check(lib().fus_model_init(self.h))
+
+    def set_state(self, u=None, v=None):
+        for which, a in ((_abi.FUS_U, u), (_abi.FUS_V, v)):
+            if a is not None:
+                a = np.ascontiguousarray(_array(a), dtype=self.data.dtype)
+                check(lib().fus_model_set(self.h, C.c_int(which), ptr(a), C.c_int(_abi.FUS_HOST)))
+
+    def _pull(self):
+        check(lib().fus_model_get(self.h, C.c_int(_abi.FUS_U), ptr(self.u_n.x.array), C.c_int(_abi.FUS_HOST)))
+        check(lib().fus_model_get(self.h, C.c_int(_abi.FUS_V), ptr(self.v_n.x.array), C.c_int(_abi.FUS_HOST)))
+
+    def rk(self, t0: float, tf: float):
+        """Runge-Kutta solve from t0 to tf; returns (u_n, v_n, t) like _linear.py:430-513."""
+        n = C.c_int64()
+        check(lib().fus_model_rk4(self.h, C.c_double(t0), C.c_double(tf), C.c_double(self.dt), C.byref(n)))
+        self.nsteps = n.value
+        self._pull()
+        return self.u_n, self.v_n, tf
+
+    # C++-style aliases (Linear.hpp:228, 316, 318)
+    def rk4(self, t0, tf, dt):
+        self.dt = dt
+        return self.rk(t0, tf)
+
+    def rk4_steps(self, t0: float, dt: float, nsteps: int, sync: bool = True):
+        """Exactly nsteps steps, asynchronous unless ``sync`` (benchmark entry)."""
+        check(lib().fus_model_rk4_steps(self.h, C.c_double(t0), C.c_double(dt), C.c_int64(nsteps)))
+        if sync:
+            self.ctx.synchronize()
+
+    def u_sol(self):
+        self._pull()
+        return self.u_n
+
+    def number_of_dofs(self):
+        return self.V.dofmap.index_map.size_global
+
+    def mass_vector(self):
+        out = np.empty(self.data.ndofs, dtype=self.data.dtype)
+        check(lib().fus_model_get_mass(self.h, ptr(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            lib().fus_model_destroy(self.h)
+            self.h = C.c_void_p()

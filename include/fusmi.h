@@ -1,0 +1,159 @@
+/*
+ * fusmi.h -- C ABI of libfusmi, the MI355X-native drop-in for the fenicsx-fus hot path:
+ * sum-factorised mass/stiffness operator action on hex spectral elements + explicit RK4
+ * stage update + shared-DOF halo exchange.  (SURVEY.md section 8b is the contract.)
+ *
+ * Each entry point names the reference interface it replaces (paths relative to the reference
+ * repository adeebkor/fenicsx-fus @ 2024-10-08).  Plain pointers and sizes only; no C++ or
+ * torch types cross this boundary.  All functions return FUS_OK (0) or a negative error code;
+ * fus_last_error() returns the message of the calling thread's last failure.  Handles are not
+ * thread-safe: one ctx/op/model per GPU per thread, like the reference's one object per MPI rank
+ * (the reference operator holds mutable scratch, spectral_op.hpp:267-283).
+ *
+ * The library REQUIRES a HIP device: there is no CPU fallback.  Calls that need the device fail
+ * with FUS_ERR_HIP when none is present.
+ */
+#ifndef FUSMI_H
+#define FUSMI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FUS_OK 0
+#define FUS_ERR_ARG (-1)     /* invalid argument / unsupported P, tdim, dtype, geometry order */
+#define FUS_ERR_HIP (-2)     /* HIP runtime error (including: no device) */
+#define FUS_ERR_RCCL (-3)    /* RCCL error */
+#define FUS_ERR_STATE (-4)   /* call sequence error (e.g. model used before init) */
+#define FUS_ERR_LIMIT (-5)   /* a block does not fit the 160 KB LDS budget / index overflow */
+
+enum { FUS_F32 = 0, FUS_F64 = 1 };           /* scalar type T of the reference templates */
+enum { FUS_HOST = 0, FUS_DEVICE = 1 };       /* memory space of caller vectors */
+enum { FUS_LINEAR = 0, FUS_LOSSY = 1, FUS_WESTERVELT = 2 };
+enum { FUS_U = 0, FUS_V = 1 };
+
+typedef struct fus_ctx fus_ctx;
+typedef struct fus_op fus_op;
+typedef struct fus_model fus_model;
+
+const char* fus_last_error(void);
+/* ABI version, for the binding to check. */
+int fus_version(void);
+
+/* ---- context --------------------------------------------------------------------------------
+ * Replaces the implicit per-rank process state of the reference (MPI_COMM_WORLD rank,
+ * Linear.hpp:64-65).  Binds to HIP device `device`, creates the compute and comm streams. */
+int fus_init(int device, fus_ctx** ctx);
+int fus_finalize(fus_ctx* ctx);
+int fus_synchronize(fus_ctx* ctx);
+/* Tunables, set before fus_op_create: "block_elems" (elements per LDS block, default 64),
+ * "waves" (waves per workgroup, default 4).  Unknown keys -> FUS_ERR_ARG. */
+int fus_set_option(fus_ctx* ctx, const char* key, int64_t value);
+
+/* Multi-GPU: one process per GPU.  fus_comm_unique_id fills a 128-byte RCCL id on rank 0; the
+ * caller broadcasts it (any transport) and every rank calls fus_comm_init.  Replaces
+ * MPI_Init/MPI_COMM_WORLD inside PetscInitialize (BM7-SC1/main.cpp:22). */
+int fus_comm_unique_id(void* id128);
+int fus_comm_init(fus_ctx* ctx, int rank, int nranks, const void* id128);
+
+/* ---- operator data ------------------------------------------------------------------------
+ * Replaces the constructors StiffnessSpectral3D<T,P>(V) / MassSpectral3D<T,P>(V)
+ * (cpp/fenicsx-sf/common/spectral_op.hpp:135-171, :32-63): takes the tensor-ordered cell dofmap
+ * (what reorder_dofmap, permute.hpp:15-42, produces), the 1-D node coordinates on [0,1] in the
+ * caller's local order (any order; the library derives GLL weights and the derivative table
+ * for it, replacing tabulate_1d precompute.hpp:217-234) and the mesh geometry, and computes on
+ * the device the scaled geometric factors G = J^-1 J^-T |detJ| w and |detJ| w
+ * (compute_scaled_geometrical_factor / _jacobian_determinant, precompute.hpp:101-213, 33-94).
+ * One object serves both operators (the reference builds one per operator, Lossy.hpp:152-153).
+ *   tdim        3 (hexahedra).  2-D (quadrilaterals, fenicsx-sf-naive) is not offloaded.
+ *   P           polynomial degree 2..7; N = P+1 nodes per direction
+ *   dtype       FUS_F64 | FUS_F32: type of geom_x and of every vector/coefficient argument later
+ *   tensor_dofmap  int32[ncells * N^3], local DOF indices < ndofs, x-slowest tensor order
+ *   nodes1d     double[N]
+ *   geom_x      T[nnodes * 3]; geom_dofmap int32[ncells * 8], vertex order v = vx + 2vy + 4vz
+ *   geom_order  1 (trilinear).  Higher-order geometry -> FUS_ERR_ARG.
+ * All arrays are caller-owned host memory, copied during the call. */
+int fus_op_create(fus_ctx* ctx, int tdim, int P, int dtype, int64_t ncells, int64_t ndofs,
+                  const int32_t* tensor_dofmap, const double* nodes1d, const void* geom_x,
+                  int64_t nnodes, const int32_t* geom_dofmap, int geom_order, fus_op** op);
+int fus_op_destroy(fus_op* op);
+
+/* y += K(coeffs) x.  Replaces StiffnessSpectral3D::operator()(x, coeffs, y)
+ * (spectral_op.hpp:173-243): y is ACCUMULATED, x must hold every local DOF value (the caller's
+ * scatter_fwd, Linear.hpp:196), coeffs has one scalar per local cell.  No inter-rank reduction is
+ * done (the caller's scatter_rev, Linear.hpp:206).  x, coeffs, y: T arrays in `space`. */
+int fus_stiffness_apply(fus_op* op, const void* x, const void* coeffs, void* y, int space);
+/* y += M(coeffs) x.  Replaces MassSpectral3D::operator() (spectral_op.hpp:69-86). */
+int fus_mass_apply(fus_op* op, const void* x, const void* coeffs, void* y, int space);
+
+/* Inspection (parity tests): geometry factors in the REFERENCE layout G[cell][point][6]
+ * (xx,xy,xz,yy,yz,zz), detJ[cell][point] (precompute.hpp:198-208); host T arrays, may be NULL. */
+int fus_op_get_geometry(fus_op* op, void* G, void* detJ);
+/* 1-D tables in the caller's node order: weights[N], dphi[N*N] row = point (spectral_op.hpp:168). */
+int fus_op_get_tables(fus_op* op, double* weights, double* dphi);
+/* Layout statistics: out[0]=nblocks out[1]=interior dofs out[2]=shared dofs out[3]=(block,dof)
+ * pairs out[4]=max local dofs per block out[5]=unique block shapes out[6]=LDS bytes per block
+ * out[7]=padded internal vector length. */
+int fus_op_info(fus_op* op, int64_t out[8]);
+
+/* out[dof] += cellcoef[cell] * |J_facet| w_a w_b at the GLL nodes of each listed boundary facet,
+ * facets given as (cell, local facet) pairs in DOLFINx numbering (hex: 0:z=0 1:y=0 2:x=0 3:x=1
+ * 4:y=1 5:z=1), the pairs fem::compute_integration_domains returns (Linear.hpp:113-118).
+ * Replaces the FFCx facet kernels of the GLL-collocated forms L/a (SC1-BM1/forms.py:36-39,
+ * BM7-SC1/forms.py:37-42), which are diagonal.  Host arrays; out is T[ndofs]. */
+int fus_facet_diag(fus_op* op, int64_t nfacets, const int32_t* facet_cells,
+                   const int32_t* facet_local, const void* cellcoef, void* out);
+
+/* Shared-DOF description for >1 rank (replaces the IndexMap ghost/owner data behind
+ * la::Vector::scatter_fwd/scatter_rev, Linear.hpp:196-206): for neighbour k, the local DOF
+ * indices shared with rank ranks[k], counts[k] of them, concatenated in dof_idx; both sides
+ * must list a shared set in the same (global id) order. */
+int fus_op_set_neighbours(fus_op* op, int nneigh, const int32_t* ranks, const int64_t* counts,
+                          const int32_t* dof_idx);
+
+/* ---- model ------------------------------------------------------------------------------------
+ * Replaces LinearSpectral3D<T,P>(element, mesh, facet_tags, c0, rho0, freq, amp, speed)
+ * (Linear.hpp:55-158): c0, rho0 are the DG0 arrays (T[ncells]); boundary facets as
+ * (cell, local facet, tag) with tag 1 = source, 2 = absorbing (forms.py:38-39).  Builds the lumped
+ * mass m (Linear.hpp:127-134) and the operator coefficient -1/rho (:154-155) on the device.
+ * delta0/beta0 are reserved for FUS_LOSSY / FUS_WESTERVELT (must be NULL for FUS_LINEAR). */
+int fus_model_create(fus_ctx* ctx, int kind, fus_op* op, const void* c0, const void* rho0,
+                     const void* delta0, const void* beta0, int64_t nfacets,
+                     const int32_t* facet_cells, const int32_t* facet_local,
+                     const int32_t* facet_tags, double freq, double amp, double speed,
+                     fus_model** model);
+int fus_model_destroy(fus_model* model);
+/* u_n = v_n = 0 (Linear.hpp:161-164). */
+int fus_model_init(fus_model* model);
+/* Classical RK4 from t0 to tf with step dt, `while (t < tf) { dt = min(dt, tf - t); ... }`
+ * (Linear.hpp:228-314); *nsteps receives the number of steps taken (may be NULL). */
+int fus_model_rk4(fus_model* model, double t0, double tf, double dt, int64_t* nsteps);
+/* Exactly nsteps full steps of size dt starting at t0 (benchmark entry; same stage arithmetic). */
+int fus_model_rk4_steps(fus_model* model, double t0, double dt, int64_t nsteps);
+/* Copy u_n (FUS_U) or v_n (FUS_V) out / in, caller DOF numbering, T[ndofs] in `space`
+ * (u_sol(), Linear.hpp:316). */
+int fus_model_get(fus_model* model, int which, void* out, int space);
+int fus_model_set(fus_model* model, int which, const void* in, int space);
+/* Lumped mass vector m in caller numbering (host T[ndofs]); parity inspection. */
+int fus_model_get_mass(fus_model* model, void* out);
+int64_t fus_model_ndofs(fus_model* model); /* number_of_dofs(), Linear.hpp:318 (local) */
+
+/* ---- measurement -----------------------------------------------------------------------------
+ * HIP-event timing of the library's own kernels on the stream they run on.  Names:
+ * "stiffness" (block operator kernel), "shared" (shared-DOF reduction), "stage" (fused RK stage
+ * update), "boundary", "halo".  total_ms/count accumulate since the last enable. */
+int fus_profile_enable(fus_ctx* ctx, int on);
+int fus_profile_get(fus_ctx* ctx, const char* name, double* total_ms, int64_t* count);
+
+/* Host-only layout builder (no device needed): runs the block partitioner / DOF renumbering on
+ * a dofmap and returns statistics as fus_op_info does; used by the CPU test-suite. */
+int fus_layout_check(int P, int64_t ncells, int64_t ndofs, const int32_t* tensor_dofmap,
+                     const double* centroids /* [ncells*3] */, int block_elems, int waves,
+                     int64_t out[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

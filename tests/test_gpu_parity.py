@@ -1,0 +1,212 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  fp64 tolerances: 1e-12 relative per operator action,
+1e-10 after 20 RK4 steps; fp32: 1e-5."""
+import numpy as np
+import pytest
+
+import fenicsxfus_amd as fa
+from fenicsxfus_amd import FacetTags, tag_box_boundary
+from util import Problem
+
+pytestmark = pytest.mark.gpu
+
+TOL_OP = 1e-12
+TOL_RK = 1e-10
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = fa.Context(0)
+    yield c
+
+
+def relmax(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("P", [2, 3, 4, 5, 6, 7])
+def test_tables_and_geometry(orc, ctx, P):
+    pr = Problem(orc, (3, 4, 2), P, hi=[1.5, 1.0, 0.8], perturb=0.15)
+    d = fa.SpectralOperatorData(pr.V, ctx)
+    w, D = d.tables()
+    assert np.allclose(w, pr.wts, rtol=0, atol=1e-15) and np.allclose(D, pr.D, rtol=0, atol=1e-11)
+    G, dJ = d.geometry()
+    assert relmax(G, pr.G) < 1e-13 and relmax(dJ, pr.detJ) < 1e-13
+    d.close()
+
+
+@pytest.mark.parametrize("P", [2, 3, 4, 5, 6, 7])
+@pytest.mark.parametrize("perturb", [0.0, 0.15])
+def test_stiffness_and_mass_vs_oracle(orc, ctx, P, perturb):
+    n = (6, 5, 4) if P <= 4 else (3, 3, 2)
+    pr = Problem(orc, n, P, hi=[1.5, 1.0, 0.8], perturb=perturb)
+    rng = np.random.default_rng(P)
+    x = rng.standard_normal(pr.ndofs)
+    coef = rng.uniform(0.5, 2.0, pr.mesh.num_cells)
+    d = fa.SpectralOperatorData(pr.V, ctx)
+    y0 = rng.standard_normal(pr.ndofs)          # y is accumulated, not overwritten
+    y = fa.StiffnessSpectral3D(pr.V, d)(x, coef, y0.copy())
+    ref = y0 + pr.K(x, coef)
+    assert relmax(y, ref) < TOL_OP
+    ym = fa.MassSpectral3D(pr.V, d)(x, coef, y0.copy())
+    assert relmax(ym, y0 + pr.M(x, coef)) < 1e-14
+    d.close()
+
+
+@pytest.mark.parametrize("be,w", [(16, 1), (16, 2), (7, 4), (64, 4), (200, 4)])
+def test_block_shapes_and_waves(orc, be, w):
+    # ragged blocks / single-wave workgroups / one block for the whole mesh
+    pr = Problem(orc, (5, 4, 3), 4, perturb=0.1)
+    c = fa.Context(0, block_elems=be, waves=w)
+    d = fa.SpectralOperatorData(pr.V, c)
+    x = np.random.default_rng(0).standard_normal(pr.ndofs)
+    coef = np.full(pr.mesh.num_cells, -1.0 / 3)
+    y = d.stiffness(x, coef, np.zeros(pr.ndofs))
+    assert relmax(y, pr.K(x, coef)) < TOL_OP
+    d.close()
+    c.close()
+
+
+def test_reference_operator_test_recipe(orc, ctx):
+    # cpp/fenicsx-sf/tests/test_operators3d/main.cpp:27-38,60-67,78-79,85,129: unit cube 20^3, P=4,
+    # u = sin(x) cos(pi y), c0 = 1.5e-3, rho0 = 1e-3, mass coeff 1/(rho c^2), stiffness coeff -1/rho
+    pr = Problem(orc, (20, 20, 20), 4)
+    X = pr.V.tabulate_dof_coordinates()
+    u = np.sin(X[:, 0]) * np.cos(np.pi * X[:, 1])
+    nc = pr.mesh.num_cells
+    c0, rho0 = 1.5e-3, 1e-3
+    d = fa.SpectralOperatorData(pr.V, ctx)
+    m1 = d.mass(u, np.full(nc, 1 / rho0 / c0 / c0), np.zeros(pr.ndofs))
+    s1 = d.stiffness(u, np.full(nc, -1 / rho0), np.zeros(pr.ndofs))
+    assert relmax(m1, pr.M(u, np.full(nc, 1 / rho0 / c0 / c0))) < 1e-14
+    assert relmax(s1, pr.K(u, np.full(nc, -1 / rho0), fast=True)) < TOL_OP
+    d.close()
+
+
+def test_node_order_invariance_gpu(orc, ctx):
+    P = 4
+    order = np.r_[0, P, 1:P]          # endpoints first (Basix-like 1-D order)
+    a = Problem(orc, (3, 3, 3), P, perturb=0.1)
+    b = Problem(orc, (3, 3, 3), P, perturb=0.1, node_order=order)
+    x = np.random.default_rng(1).standard_normal(a.ndofs)
+    coef = np.ones(a.mesh.num_cells)
+    da, db = fa.SpectralOperatorData(a.V, ctx), fa.SpectralOperatorData(b.V, ctx)
+    ya = da.stiffness(x, coef, np.zeros(a.ndofs))
+    yb = db.stiffness(x, coef, np.zeros(a.ndofs))
+    assert relmax(yb, ya) < TOL_OP and relmax(ya, a.K(x)) < TOL_OP
+    da.close(), db.close()
+
+
+def test_bitwise_reproducible(orc, ctx):
+    pr = Problem(orc, (8, 8, 8), 4, perturb=0.1)
+    d = fa.SpectralOperatorData(pr.V, ctx)
+    x = np.random.default_rng(2).standard_normal(pr.ndofs)
+    coef = np.ones(pr.mesh.num_cells)
+    y1 = d.stiffness(x, coef, np.zeros(pr.ndofs))
+    y2 = d.stiffness(x, coef, np.zeros(pr.ndofs))
+    assert np.array_equal(y1, y2)
+    d.close()
+
+
+def test_fp32_operator(orc, ctx):
+    pr = Problem(orc, (4, 4, 4), 4, perturb=0.1, dtype=np.float32)
+    pr64 = Problem(orc, (4, 4, 4), 4, perturb=0.1)
+    x = np.random.default_rng(3).standard_normal(pr.ndofs).astype(np.float32)
+    coef = np.ones(pr.mesh.num_cells, np.float32)
+    d = fa.SpectralOperatorData(pr.V, ctx)
+    y = d.stiffness(x, coef, np.zeros(pr.ndofs, np.float32))
+    ref = pr64.K(x.astype(np.float64))
+    assert relmax(y, ref) < 1e-5
+    assert relmax(y, pr.K(x, coef)) < 1e-5
+    d.close()
+
+
+def _linear_setup(orc, ctx, n, P, hi, perturb=0.0, c0=1500.0, rho0=1000.0, hetero=False):
+    pr = Problem(orc, n, P, hi=hi, perturb=perturb)
+    nc = pr.mesh.num_cells
+    c = np.full(nc, c0)
+    rho = np.full(nc, rho0)
+    if hetero:   # cortical-bone slab, BM7-SC1/main.cpp:37-40
+        cx = pr.mesh.cell_centroids()[:, 0]
+        sel = (cx > 0.4 * hi[0]) & (cx < 0.6 * hi[0])
+        c[sel], rho[sel] = 2800.0, 1850.0
+    tags = tag_box_boundary(pr.mesh)
+    return pr, c, rho, tags
+
+
+@pytest.mark.parametrize("hetero,perturb", [(False, 0.0), (True, 0.1)])
+def test_linear_rk4_vs_oracle(orc, ctx, hetero, perturb):
+    L = 0.012
+    P, n = 4, (6, 6, 6)
+    pr, c, rho, tags = _linear_setup(orc, ctx, n, P, [L, L, L], perturb=perturb, hetero=hetero)
+    f0, p0, s0 = 0.5e6, 60000.0, 1500.0
+    h = L / n[0]
+    dt = 0.5 * h / (c.max() * P**2)
+    nsteps = 20
+    m, src, absb, coeff = pr.linear_model_vectors(c, rho, tags)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    ns = orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, f0, p0, s0, 0.0, nsteps * dt * (1 - 1e-9),
+                        dt, u, v)
+    assert ns == nsteps
+    model = fa.LinearSpectralExplicit(pr.mesh, tags, P, c, rho, f0, p0, s0, 4, dt, V=pr.V, ctx=ctx)
+    assert relmax(model.mass_vector(), m) < 1e-14
+    model.init()
+    un, vn, _ = model.rk(0.0, nsteps * dt * (1 - 1e-9))
+    assert model.nsteps == nsteps
+    assert np.abs(u).max() > 0
+    assert relmax(un.x.array, u) < TOL_RK and relmax(vn.x.array, v) < TOL_RK
+    # exact-step entry gives the same state
+    model.init()
+    model.rk4_steps(0.0, dt, nsteps - 1)
+    model.rk4_steps((nsteps - 1) * dt, dt * (1 - 1e-9 * nsteps), 1)
+    model.close()
+
+
+def test_plane_wave_vs_analytical_gpu(orc, ctx):
+    # python/tests/test_linearspectral_1d.py:12-107 (degree 4, epw 4): L2 error < 1e-3
+    f0, c0, rho0, L, degree, epw = 10.0, 1.0, 4.0, 1.0, 4, 4
+    p0 = rho0 * c0
+    nx = int(epw * L / (c0 / f0) + 1)
+    h = L / nx
+    pr = Problem(orc, (nx, 1, 1), degree, hi=[L, h, h])
+    cells, lf, ax, sd = pr.mesh.exterior_facets()
+    keep = ax == 0
+    tags = FacetTags(cells[keep], lf[keep], np.where(sd[keep] == 0, 1, 2))
+    tend = L / c0 + 16 / f0
+    dt = 0.9 * h / (c0 * degree**2)
+    nc = pr.mesh.num_cells
+    model = fa.LinearSpectralExplicit(pr.mesh, tags, degree, np.full(nc, c0), np.full(nc, rho0), f0, p0, c0, 4, dt,
+                                      V=pr.V, ctx=ctx)
+    model.init()
+    un, _, _ = model.rk(0.0, tend)
+    X = pr.V.tabulate_dof_coordinates()[:, 0]
+    ue = p0 * np.sin(2 * np.pi * f0 * (tend - X / c0)) * (tend - X / c0 > 0)
+    w = pr.M(np.ones(pr.ndofs))
+    err = np.sqrt(w @ (un.x.array - ue) ** 2) / np.sqrt(w @ ue**2)
+    assert err < 1e-3, err
+    model.close()
+
+
+def test_full_size_properties(orc, ctx):
+    """BASELINE config 2 (64^3 hex, p=4, fp64): size-independent properties of the operator --
+    K 1 = 0, sum(K x) = 0, symmetry, sum(m) = volume/(rho c^2) -- at the full benchmark size."""
+    L = 0.12
+    m = fa.BoxMesh([0, 0, 0], [L, L, L], (64, 64, 64))
+    V = fa.FunctionSpace(m, 4)
+    d = fa.SpectralOperatorData(V, ctx)
+    n, nc = V.num_dofs, m.num_cells
+    assert n == 16974593
+    rng = np.random.default_rng(0)
+    x, z = rng.standard_normal(n), rng.standard_normal(n)
+    coef = np.full(nc, -1e-3)
+    y = d.stiffness(x, coef, np.zeros(n))
+    scale = np.abs(y).max()
+    assert np.abs(d.stiffness(np.ones(n), coef, np.zeros(n))).max() < 1e-11 * scale
+    assert abs(y.sum()) < 1e-9 * np.abs(y).sum()
+    yz = d.stiffness(z, coef, np.zeros(n))
+    assert abs(z @ y - x @ yz) < 1e-10 * abs(z @ y)
+    mm = d.mass(np.ones(n), np.full(nc, 1.0), np.zeros(n))
+    assert abs(mm.sum() - L**3) < 1e-12 * L**3
+    info = d.info()
+    assert info["nblocks"] == 4096 and info["shapes"] == 27
+    d.close()

@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DOF-updates/s of the Linear RK4 step (p=4 hex, fp64) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full classical RK4 step (4 stages: stiffness action + shared-DOF reduction +
+boundary terms + fused stage update) of the Linear acoustic model on BASELINE.json configs[1]:
+3-D homogeneous water box, 64^3 hexes, p=4, fp64 (16 974 593 DOFs per GPU).  At N>1 each rank owns
+a 64^3 x-slab of a (64 N) x 64 x 64 box (weak scaling) and exchanges one interface plane per
+neighbour per stage over RCCL.  All state is resident in HBM when the timed region starts.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) including
+  roofline     -- the dominant kernel (block stiffness operator): algorithmic bytes per launch
+                  (SURVEY 8d stiffness term: rho_e (s + 4 + 6 s) + s per DOF) / its average
+                  duration measured with HIP events on the library's stream
+  cpu_baseline -- the CPU oracle (port of the reference loop, -Ofast) timed on this host
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "fenicsx-fus_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+
+def workload(n_per_gpu, P, rank, size, dtype=np.float64):
+    """SURVEY 8d synthetic inputs: box edge 0.12 m per 64 cells, water, source on x=0 (tag 1),
+    absorbing elsewhere (tag 2), f = 0.5 MHz, p0 = 60 kPa, CFL 0.5 snapped to steps/period."""
+    import fenicsxfus_amd as fa
+
+    L1 = 0.12 * n_per_gpu / 64.0
+    mesh = fa.BoxMesh([0, 0, 0], [L1 * size, L1, L1], (n_per_gpu * size, n_per_gpu, n_per_gpu), rank=rank,
+                      size=size, dtype=dtype)
+    V = fa.FunctionSpace(mesh, P)
+    tags = fa.tag_box_boundary(mesh)
+    c0, rho0, freq, p0 = 1500.0, 1000.0, 0.5e6, 60000.0
+    h = L1 / n_per_gpu
+    dt = 0.5 * h / (c0 * P**2)
+    period = 1.0 / freq
+    dt = period / np.ceil(period / dt)
+    return mesh, V, tags, c0, rho0, freq, p0, dt
+
+
+def cpu_baseline(P, n, steps):
+    """Oracle (restatement of Linear.hpp:228-314 + spectral_op.hpp:173-243, -Ofast -march=native,
+    one thread) on a bounded sample of the same workload."""
+    import oracle
+
+    oracle.build()
+    import fenicsxfus_amd as fa
+
+    mesh, V, tags, c0, rho0, freq, p0, dt = workload(n, P, 0, 1)
+    nc, nd = mesh.num_cells, V.num_dofs
+    wts = oracle.gll_weights_at(V.nodes1d)
+    D = oracle.dphi(V.nodes1d)
+    G, detJ = oracle.geometry(3, mesh.geometry.x, mesh.geometry.dofmap, V.nodes1d, wts)
+    c, r = np.full(nc, c0), np.full(nc, rho0)
+    m = oracle.mass(3, P + 1, V.tensor_dofmap, detJ, 1.0 / (r * c * c), np.ones(nd), np.zeros(nd))
+    fd = lambda tag, cc: oracle.facet_diag(3, tags.cells[tags.find(tag)], tags.local_facets[tags.find(tag)], cc,  # noqa
+                                           mesh.geometry.x, mesh.geometry.dofmap, V.nodes1d, wts, V.tensor_dofmap, nd)
+    src, absb = fd(1, 1.0 / r), fd(2, 1.0 / (r * c))
+    u, v = np.zeros(nd), np.zeros(nd)
+    t0 = time.perf_counter()
+    ns = oracle.linear_rk4(3, P + 1, V.tensor_dofmap, G, D, -1.0 / r, m, src, absb, freq, p0, c0, 0.0,
+                           steps * dt * (1 - 1e-9), dt, u, v, fast=True)
+    el = time.perf_counter() - t0
+    return {"value": nd * ns / el, "unit": "DOF-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{n}^3 hex p={P} fp64 ({nd} DOFs), {ns} RK4 steps, {el:.1f} s, oracle -Ofast 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=64, help="cells per axis per GPU")
+    ap.add_argument("--P", type=int, default=4)
+    ap.add_argument("--block-elems", type=int, default=None)
+    ap.add_argument("--waves", type=int, default=None)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-n", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=10)
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    torch.cuda.set_device(local_rank)
+
+    import fenicsxfus_amd as fa
+
+    ctx = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        ids = [fa.Context.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        ctx.comm_init(rank, world, ids[0])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ctx.synchronize()
+
+    P, n = args.P, args.n
+    mesh, V, tags, c0, rho0, freq, p0, dt = workload(n, P, rank, world)
+    nc = mesh.num_cells
+    model = fa.LinearSpectralExplicit(mesh, tags, P, np.full(nc, c0), np.full(nc, rho0), freq, p0, c0, 4, dt, V=V,
+                                      ctx=ctx)
+    model.init()
+    ndofs_global = V.dofmap.index_map.size_global
+    info = model.data.info()
+
+    model.rk4_steps(0.0, dt, args.warmup)
+    ctx.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    model.rk4_steps(args.warmup * dt, dt, args.steps, sync=False)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    prof = {k: ctx.profile_get(k) for k in ("stiffness", "shared", "boundary", "stage", "halo")}
+    ctx.profile_enable(False)
+
+    u = model.u_sol().x.array
+    finite = bool(np.isfinite(u).all()) and float(np.abs(u).max()) > 0.0
+
+    if rank == 0:
+        s = 8
+        N3 = (P + 1) ** 3
+        ndl = V.num_dofs
+        rho_e = nc * N3 / ndl
+        # per stage  stiffness = rho_e (s + 4 + 6 s) + s ; stage update = 12 s
+        b_stiff = rho_e * (s + 4 + 6 * s) + s
+        b_general = 4 * (b_stiff + 12 * s)
+        k_ms, k_cnt = prof["stiffness"]
+        avg_ms = k_ms / max(k_cnt, 1)
+        achieved = b_stiff * ndl / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        value = ndofs_global * args.steps / elapsed
+        out = {
+            "metric": "DOF-updates/sec (RK4 step) at p=4 hex fp64",
+            "value": value,
+            "unit": "DOF-updates/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"3D homogeneous wave, {n}^3 hex p={P} fp64 per GPU, Linear RK4 "
+                                   f"(BASELINE.json configs[1])", "ndofs_global": int(ndofs_global),
+                       "cells_per_gpu": int(nc), "geometry": "general (G streamed, 6 fp64 per point)",
+                       "partition": f"x-slabs x{world}", "blocks": info["nblocks"],
+                       "lds_bytes_per_block": info["lds_bytes"], "dt": dt},
+            "roofline": {"bound": "hbm", "kernel": "k_block_op<double,4,stiffness>", "achieved": achieved,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                         "algorithmic_bytes_per_launch": b_stiff * ndl, "avg_launch_ms": avg_ms,
+                         "launches": k_cnt},
+            "step_roofline": {"algorithmic_bytes_per_dof_update": b_general,
+                              "achieved_GBps": b_general * value / world / 1e9,
+                              "frac_of_8TBps": b_general * value / world / 8e12},
+            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "finite_nonzero_solution": finite,
+        }
+        if not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(P, args.cpu_n, args.cpu_steps)
+        print(json.dumps(out))
+    model.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

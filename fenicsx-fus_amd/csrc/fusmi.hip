@@ -69,7 +69,7 @@ struct fus_ctx
 {
   int device = 0;
   hipStream_t stream = nullptr;
-  int block_elems = 64, waves = 4;
+  int block_elems = 32, waves = 4;  // measured best on MI355X at p=4 fp64 (profiles/r01_block_sweep.txt)
   bool prof = false;
   std::map<std::string, Prof> profs;
   ncclComm_t comm = nullptr;
@@ -300,6 +300,7 @@ static int op_setup_device(fus_op* op)
   FUSCHK(upload(pool, &d_sh_off, L.blk_sh_off, st));
   FUSCHK(upload(pool, &d_sh_gidx, L.sh_gidx, st));
   FUSCHK(upload(pool, &d_rounds, L.rounds, st));
+  L.ldm.resize((L.ldm.size() + 15) & ~(size_t)15);  // 16-byte tail for the vector copy
   FUSCHK(upload(pool, &d_ldm, L.ldm, st));
   FUSCHK(upload(pool, &op->d_cell_perm, L.cell_perm, st));
   FUSCHK(upload(pool, &op->d_dof_perm, L.dof_perm, st));
@@ -310,7 +311,8 @@ static int op_setup_device(fus_op* op)
   op->A.rounds = d_rounds, op->A.ldm = d_ldm, op->A.nblocks = L.nblocks;
   op->A.lds_nloc = (L.max_nloc + 1) & ~1;
   op->A.waves = L.waves;
-  op->lds_bytes = (size_t)2 * op->A.lds_nloc * sizeof(T) + (size_t)L.slots * 2 * Nd * sizeof(T);
+  op->A.lds_nelem = (L.max_nelem + 7) & ~7;
+  op->lds_bytes = L.lds_bytes(sizeof(T));
   if (op->lds_bytes > 160 * 1024)
     return fail(FUS_ERR_LIMIT, "block does not fit 160 KB of LDS; lower block_elems");
 
@@ -909,7 +911,7 @@ static void layout_info(const Layout& L, size_t ts, int64_t out[8])
 {
   out[0] = L.nblocks, out[1] = L.n_interior, out[2] = L.n_shared, out[3] = L.npairs;
   out[4] = L.max_nloc, out[5] = (int64_t)L.shapes.size();
-  out[6] = (int64_t)((size_t)2 * ((L.max_nloc + 1) & ~1) * ts + (size_t)L.slots * 2 * L.Nd * ts);
+  out[6] = (int64_t)L.lds_bytes(ts);
   out[7] = L.n_internal;
 }
 

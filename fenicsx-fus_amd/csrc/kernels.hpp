@@ -42,6 +42,7 @@ struct BlockArgs
   const uint16_t* ldm;
   int32_t nblocks;
   int32_t lds_nloc;  // LDS array length (>= max nloc, even)
+  int32_t lds_nelem; // LDS per-element table length (>= max elements per block, multiple of 8)
   int32_t waves;
 };
 
@@ -83,6 +84,175 @@ enum
 };
 
 // ---------------------------------------------------------------------------------------------
+// Per-element inputs fetched from HBM one round ahead of their use (software pipeline):
+// local dof indices, geometry factors (stiffness) or detJw (mass), cell coefficient.
+template <typename T, int N, int OP>
+struct ElemIn
+{
+  typedef typename GLoad<T, N>::type GV;
+  static constexpr int NV = GLoad<T, N>::NV;
+  int er;
+  GV g[OP == OP_STIFFNESS ? NV : 1];
+  T dj[OP == OP_MASS ? N : 1];
+};
+
+template <typename T, int N, int OP>
+__device__ __forceinline__ void elem_fetch(ElemIn<T, N, OP>& in, int er, const T* __restrict__ geo,
+                                           int elem_off, int p)
+{
+  constexpr int N2 = N * N, Nd = N * N * N;
+  constexpr int VW = GLoad<T, N>::VW, NV = GLoad<T, N>::NV;
+  typedef typename GLoad<T, N>::type GV;
+  in.er = er;
+  if (er >= 0)
+  {
+    const int64_t e = elem_off + er;
+    if (OP == OP_STIFFNESS)
+    {
+#if defined(FUS_ABLATE) && FUS_ABLATE == 2  // timing experiment: no geometry stream
+      const T* Ge = geo + (e & 7) * (6 * Nd);
+#else
+      const T* Ge = geo + e * (6 * Nd);
+#endif
+#pragma unroll
+      for (int t = 0; t < NV; ++t)
+        in.g[t] = *reinterpret_cast<const GV*>(Ge + (size_t)(t * N2 + p) * VW);
+    }
+    else
+    {
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        in.dj[a] = geo[e * Nd + a * N2 + p];
+    }
+  }
+}
+
+// One element's operator action, accumulated into the block's LDS vector y_l.
+template <typename T, int N, int OP>
+__device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP>& in, const DTab<T, N>& Dk,
+                                             const T (&Drb)[N], const T (&Drc)[N], const T (&Dcb)[N],
+                                             const T (&Dcc)[N], const T* __restrict__ x_l,
+                                             T* __restrict__ y_l, T* __restrict__ sA,
+                                             T* __restrict__ sB, const uint16_t* __restrict__ ldm_l,
+                                             const T* __restrict__ cf_l, int p, int b, int c)
+{
+  constexpr int N2 = N * N, Nd = N * N * N;
+  constexpr int VW = GLoad<T, N>::VW;
+  if (in.er < 0)
+    return;
+  int li[N];
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    li[a] = ldm_l[in.er * Nd + a * N2 + p];
+  const T cf = cf_l[in.er];
+  T Y[N];
+#if defined(FUS_ABLATE) && FUS_ABLATE == 1  // timing experiment: loads only, no contractions
+  if (OP == OP_STIFFNESS)
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      T acc = x_l[li[a]];
+#pragma unroll
+      for (int gi = 0; gi < 6; ++gi)
+      {
+        const int v = gi * N + a;
+        acc += in.g[v / VW][v % VW];
+      }
+      Y[a] = acc * cf;
+    }
+  }
+  else
+#endif
+  if (OP == OP_STIFFNESS)
+  {
+    T X[N], F0[N], F1[N], F2[N];
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      X[a] = x_l[li[a]];
+    // derivative along tensor index 0: registers only (spectral_op.hpp:194-196)
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+    {
+      T acc = T(0);
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        acc += Dk.d[q * N + i] * X[i];
+      F0[q] = acc;
+    }
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      sA[a * N2 + p] = X[a];
+    FUS_WAVE_SYNC();
+    // derivatives along tensor indices 1 and 2 (spectral_op.hpp:199-210)
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      T f1 = T(0), f2 = T(0);
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+      {
+        f1 += Drb[j] * sA[a * N2 + j * N + c];
+        f2 += Drc[j] * sA[a * N2 + b * N + j];
+      }
+      F1[a] = f1;
+      F2[a] = f2;
+    }
+    // stiffness::transform (spectral_op.hpp:113-130)
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      T G6[6];
+#pragma unroll
+      for (int gi = 0; gi < 6; ++gi)
+      {
+        const int v = gi * N + a;
+        G6[gi] = in.g[v / VW][v % VW];
+      }
+      const T w0 = F0[a], w1 = F1[a], w2 = F2[a];
+      F0[a] = cf * (G6[0] * w0 + G6[1] * w1 + G6[2] * w2);
+      F1[a] = cf * (G6[1] * w0 + G6[3] * w1 + G6[4] * w2);
+      F2[a] = cf * (G6[2] * w0 + G6[4] * w1 + G6[5] * w2);
+    }
+    FUS_WAVE_SYNC();
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      sA[a * N2 + p] = F1[a];
+      sB[a * N2 + p] = F2[a];
+    }
+    FUS_WAVE_SYNC();
+    // transposed contractions (spectral_op.hpp:222-238)
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      T acc = T(0);
+#pragma unroll
+      for (int q = 0; q < N; ++q)
+        acc += Dk.d[q * N + a] * F0[q];
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+      {
+        acc += Dcb[j] * sA[a * N2 + j * N + c];
+        acc += Dcc[j] * sB[a * N2 + b * N + j];
+      }
+      Y[a] = acc;
+    }
+  }
+  else
+  {
+    // mass::transform (spectral_op.hpp:19-26)
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      Y[a] = cf * x_l[li[a]] * in.dj[a];
+  }
+  // scatter-add into the block accumulator (spectral_op.hpp:240-241); elements of one round
+  // share no dof and rounds are ordered -> deterministic
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    y_l[li[a]] += Y[a];
+}
+
 // Block operator:  bvec[interior dofs of block] = (A x)[...],  partial[(block, shared slot)] =
 // this block's contribution to a shared dof.  x, bvec in internal numbering.
 // geo = G (6*Nd per element, per-lane vector layout) for OP_STIFFNESS, detJw (Nd per element,
@@ -95,13 +265,15 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
 {
   constexpr int N = P + 1, N2 = N * N, Nd = N * N * N;
   constexpr int EPW = (64 / N2) > 0 ? (64 / N2) : 1;
-  typedef typename GLoad<T, N>::type GV;
-  constexpr int VW = GLoad<T, N>::VW, NV = GLoad<T, N>::NV;
 
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* x_l = reinterpret_cast<T*>(smem_raw);
   T* y_l = x_l + A.lds_nloc;
   T* scratch = y_l + A.lds_nloc;
+  T* D_l = scratch + (size_t)A.waves * EPW * 2 * Nd;      // derivative table
+  T* cf_l = D_l + N2;                                       // per-element coefficient
+  uint16_t* ldm_l = reinterpret_cast<uint16_t*>(cf_l + A.lds_nelem);  // local dofmaps (16-B aligned)
+  int16_t* rt_l = reinterpret_cast<int16_t*>(ldm_l + (size_t)A.lds_nelem * Nd);
 
   const int blk = blockIdx.x;
   const int tid = threadIdx.x, nthr = blockDim.x;
@@ -110,160 +282,129 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   const int int_off = A.blk_int_off[blk];
   const int64_t sh_off = A.blk_sh_off[blk];
 
-  // ---- prologue: stage the block's dof values in LDS, clear the accumulator ----
-  for (int l = tid; l < sh.nint; l += nthr)
-  {
-    x_l[l] = x[int_off + l];
-    y_l[l] = T(0);
-  }
-  for (int l = sh.nint + tid; l < sh.nloc; l += nthr)
-  {
-    x_l[l] = x[A.sh_gidx[sh_off + (l - sh.nint)]];
-    y_l[l] = T(0);
-  }
-  __syncthreads();
-
   const int lane = tid & 63, wave = tid >> 6;
   const int s = lane / N2, p = lane - s * N2;
   const int b = p / N, c = p - b * N;
   const bool active = s < EPW;
   const int slots = A.waves * EPW;
+  const int16_t* rtab = A.rounds + sh.rounds_off + wave * EPW + (active ? s : 0);
+
+  // first round's geometry is requested before the block's dof values are staged
+  ElemIn<T, N, OP> inA, inB;
+  elem_fetch<T, N, OP>(inA, (active && sh.nrounds > 0) ? (int)rtab[0] : -1, geo, elem_off, p);
+
+  // ---- prologue: stage the block's dof values in LDS, clear the accumulator; all loads of a
+  // pass are issued before the first LDS store so one HBM round trip covers the whole block ----
+  {
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    constexpr int UN = 8;
+    const V2* xg = reinterpret_cast<const V2*>(x + int_off);  // int_off is a multiple of 16
+    const int nvec = sh.nint >> 1;
+    for (int base = tid; base < nvec; base += nthr * UN)
+    {
+      V2 v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (base + u * nthr < nvec)
+          v[u] = xg[base + u * nthr];
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (base + u * nthr < nvec)
+        {
+          reinterpret_cast<V2*>(x_l)[base + u * nthr] = v[u];
+          reinterpret_cast<V2*>(y_l)[base + u * nthr] = V2(T(0));
+        }
+    }
+    if (tid == 0 && (sh.nint & 1))
+    {
+      x_l[sh.nint - 1] = x[int_off + sh.nint - 1];
+      y_l[sh.nint - 1] = T(0);
+    }
+    const int nsh = sh.nloc - sh.nint;
+    const int32_t* gix = A.sh_gidx + sh_off;
+    for (int base = tid; base < nsh; base += nthr * UN)
+    {
+      int gi[UN];
+      T v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        gi[u] = (base + u * nthr < nsh) ? gix[base + u * nthr] : 0;
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        v[u] = x[gi[u]];
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (base + u * nthr < nsh)
+        {
+          x_l[sh.nint + base + u * nthr] = v[u];
+          y_l[sh.nint + base + u * nthr] = T(0);
+        }
+    }
+    // this block's round table -> LDS, so the per-round element lookup is not a global load that
+    // would drain the geometry prefetch queue (vmcnt retires in order)
+    for (int k = tid; k < sh.nrounds * slots; k += nthr)
+      rt_l[k] = A.rounds[sh.rounds_off + k];
+    // local dofmaps, coefficients and the derivative table likewise (LDS reads retire on lgkmcnt)
+    {
+      typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+      const int n16 = (sh.nelem * Nd * 2 + 15) >> 4;  // ldm_off is a multiple of 8 entries
+      const U4* src = reinterpret_cast<const U4*>(A.ldm + sh.ldm_off);
+      for (int k = tid; k < n16; k += nthr)
+        reinterpret_cast<U4*>(ldm_l)[k] = src[k];
+    }
+    for (int k = tid; k < sh.nelem; k += nthr)
+      cf_l[k] = coef[elem_off + k];
+    if (tid < N2)
+      D_l[tid] = Dg[tid];
+  }
+
   T* sA = scratch + (size_t)(wave * EPW + (active ? s : 0)) * 2 * Nd;
   T* sB = sA + Nd;
 
   // lane-dependent rows/columns of the derivative table (tiny, cache resident)
+  __syncthreads();
   T Drb[N], Drc[N], Dcb[N], Dcc[N];
-  if (OP == OP_STIFFNESS)
-  {
 #pragma unroll
-    for (int j = 0; j < N; ++j)
-    {
-      Drb[j] = Dg[b * N + j];
-      Drc[j] = Dg[c * N + j];
-      Dcb[j] = Dg[j * N + b];
-      Dcc[j] = Dg[j * N + c];
-    }
+  for (int j = 0; j < N; ++j)
+  {
+    Drb[j] = (OP == OP_STIFFNESS) ? D_l[b * N + j] : T(0);
+    Drc[j] = (OP == OP_STIFFNESS) ? D_l[c * N + j] : T(0);
+    Dcb[j] = (OP == OP_STIFFNESS) ? D_l[j * N + b] : T(0);
+    Dcc[j] = (OP == OP_STIFFNESS) ? D_l[j * N + c] : T(0);
   }
 
-  for (int r = 0; r < sh.nrounds; ++r)
+  // ---- rounds, two per trip: while one register set is consumed the other is in flight ----
+  for (int r = 0; r < sh.nrounds; r += 2)
   {
-    const int er = active ? (int)A.rounds[sh.rounds_off + (int64_t)r * slots + wave * EPW + s] : -1;
-    if (er >= 0)
-    {
-      const uint16_t* ldm_e = A.ldm + sh.ldm_off + (int64_t)er * Nd;
-      const int64_t e = elem_off + er;
-      int li[N];
-#pragma unroll
-      for (int a = 0; a < N; ++a)
-        li[a] = ldm_e[a * N2 + p];
-      const T cf = coef[e];
-      T Y[N];
-
-      if (OP == OP_STIFFNESS)
-      {
-        // stream this element's geometry factors (issued first, consumed after the forward pass)
-        const T* Ge = geo + e * (6 * Nd);
-        GV g[NV];
-#pragma unroll
-        for (int t = 0; t < NV; ++t)
-          g[t] = *reinterpret_cast<const GV*>(Ge + (size_t)(t * N2 + p) * VW);
-
-        T X[N], F0[N], F1[N], F2[N];
-#pragma unroll
-        for (int a = 0; a < N; ++a)
-          X[a] = x_l[li[a]];
-        // derivative along tensor index 0: registers only (spectral_op.hpp:194-196)
-#pragma unroll
-        for (int q = 0; q < N; ++q)
-        {
-          T acc = T(0);
-#pragma unroll
-          for (int i = 0; i < N; ++i)
-            acc += Dk.d[q * N + i] * X[i];
-          F0[q] = acc;
-        }
-#pragma unroll
-        for (int a = 0; a < N; ++a)
-          sA[a * N2 + p] = X[a];
-        FUS_WAVE_SYNC();
-        // derivatives along tensor indices 1 and 2 (spectral_op.hpp:199-210)
-#pragma unroll
-        for (int a = 0; a < N; ++a)
-        {
-          T f1 = T(0), f2 = T(0);
-#pragma unroll
-          for (int j = 0; j < N; ++j)
-          {
-            f1 += Drb[j] * sA[a * N2 + j * N + c];
-            f2 += Drc[j] * sA[a * N2 + b * N + j];
-          }
-          F1[a] = f1;
-          F2[a] = f2;
-        }
-        // stiffness::transform (spectral_op.hpp:113-130)
-#pragma unroll
-        for (int a = 0; a < N; ++a)
-        {
-          T G6[6];
-#pragma unroll
-          for (int gi = 0; gi < 6; ++gi)
-          {
-            const int v = gi * N + a;
-            G6[gi] = g[v / VW][v % VW];
-          }
-          const T w0 = F0[a], w1 = F1[a], w2 = F2[a];
-          F0[a] = cf * (G6[0] * w0 + G6[1] * w1 + G6[2] * w2);
-          F1[a] = cf * (G6[1] * w0 + G6[3] * w1 + G6[4] * w2);
-          F2[a] = cf * (G6[2] * w0 + G6[4] * w1 + G6[5] * w2);
-        }
-        FUS_WAVE_SYNC();
-#pragma unroll
-        for (int a = 0; a < N; ++a)
-        {
-          sA[a * N2 + p] = F1[a];
-          sB[a * N2 + p] = F2[a];
-        }
-        FUS_WAVE_SYNC();
-        // transposed contractions (spectral_op.hpp:222-238)
-#pragma unroll
-        for (int a = 0; a < N; ++a)
-        {
-          T acc = T(0);
-#pragma unroll
-          for (int q = 0; q < N; ++q)
-            acc += Dk.d[q * N + a] * F0[q];
-#pragma unroll
-          for (int j = 0; j < N; ++j)
-          {
-            acc += Dcb[j] * sA[a * N2 + j * N + c];
-            acc += Dcc[j] * sB[a * N2 + b * N + j];
-          }
-          Y[a] = acc;
-        }
-      }
-      else
-      {
-        // mass::transform (spectral_op.hpp:19-26)
-#pragma unroll
-        for (int a = 0; a < N; ++a)
-          Y[a] = cf * x_l[li[a]] * geo[e * Nd + a * N2 + p];
-      }
-      // scatter-add into the block accumulator (spectral_op.hpp:240-241); elements of one
-      // round share no dof, rounds are ordered -> deterministic
-#pragma unroll
-      for (int a = 0; a < N; ++a)
-        y_l[li[a]] += Y[a];
-    }
+    const bool has1 = r + 1 < sh.nrounds, has2 = r + 2 < sh.nrounds;
+    elem_fetch<T, N, OP>(inB, (active && has1) ? (int)rt_l[(r + 1) * slots + wave * EPW + s] : -1, geo,
+                         elem_off, p);
+    elem_compute<T, N, OP>(inA, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, p, b, c);
     if (A.waves > 1)
       __syncthreads();
+    elem_fetch<T, N, OP>(inA, (active && has2) ? (int)rt_l[(r + 2) * slots + wave * EPW + s] : -1, geo,
+                         elem_off, p);
+    if (has1)
+    {
+      elem_compute<T, N, OP>(inB, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, p, b, c);
+      if (A.waves > 1)
+        __syncthreads();
+    }
   }
   __syncthreads();
 
   // ---- epilogue: each dof written once ----
-  for (int l = tid; l < sh.nint; l += nthr)
-    bvec[int_off + l] = y_l[l];
-  for (int l = sh.nint + tid; l < sh.nloc; l += nthr)
-    partial[sh_off + (l - sh.nint)] = y_l[l];
+  {
+    typedef T V2 __attribute__((ext_vector_type(2)));
+    V2* bg = reinterpret_cast<V2*>(bvec + int_off);
+    const int nvec = sh.nint >> 1;
+    for (int i = tid; i < nvec; i += nthr)
+      bg[i] = reinterpret_cast<const V2*>(y_l)[i];
+    if (tid == 0 && (sh.nint & 1))
+      bvec[int_off + sh.nint - 1] = y_l[sh.nint - 1];
+    for (int l = sh.nint + tid; l < sh.nloc; l += nthr)
+      partial[sh_off + (l - sh.nint)] = y_l[l];
+  }
 }
 
 // bsh[s] = sum over the (block, slot) pairs of shared dof s, ascending block order

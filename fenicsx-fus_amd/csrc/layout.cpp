@@ -162,6 +162,8 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
         rmask[loc_of[d[i]]] |= (1ull << r);
     }
     const int32_t nrounds = (int32_t)rd.size();
+    L.max_rounds = std::max(L.max_rounds, nrounds);
+    L.max_nelem = std::max(L.max_nelem, nelem);
 
     // internal element order = (round, slot), compact
     std::vector<int16_t> rtab((size_t)nrounds * L.slots, (int16_t)-1);
@@ -244,6 +246,7 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
       sh.nelem = nelem, sh.nloc = nloc, sh.nint = nint, sh.nrounds = nrounds;
       sh.rounds_off = (int64_t)L.rounds.size();
       L.rounds.insert(L.rounds.end(), rtab.begin(), rtab.end());
+      L.ldm.resize((L.ldm.size() + 7) & ~(size_t)7);
       sh.ldm_off = (int64_t)L.ldm.size();
       L.ldm.insert(L.ldm.end(), key.begin() + ldm_start, key.end());
       const int32_t id = (int32_t)L.shapes.size();

@@ -51,11 +51,16 @@ struct Layout
   int64_t n_internal = 0;             // padded internal vector length (multiple of 16)
   std::vector<int64_t> sh_ptr;        // [n_shared+1] CSR: shared dof -> pair indices
   std::vector<int64_t> sh_pairs;      // [npairs] ascending block order
-  int32_t max_nloc = 0;
+  int32_t max_nloc = 0, max_rounds = 0, max_nelem = 0;
 
   size_t lds_bytes(size_t sizeofT) const
   {
-    return (size_t)2 * ((max_nloc + 1) & ~1) * sizeofT + (size_t)slots * 2 * Nd * sizeofT;
+    const size_t ne = ((size_t)max_nelem + 7) & ~(size_t)7;
+    return (size_t)2 * ((max_nloc + 1) & ~1) * sizeofT   // x_l, y_l
+           + (size_t)slots * 2 * Nd * sizeofT            // per-element exchange tiles
+           + (size_t)N * N * sizeofT + ne * sizeofT      // derivative table, coefficients
+           + ne * Nd * 2                                 // local dofmaps
+           + (size_t)max_rounds * slots * 2 + 16;        // round table
   }
 };
 

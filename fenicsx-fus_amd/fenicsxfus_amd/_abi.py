@@ -8,7 +8,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfusmi.so")
+LIB_PATH = os.environ.get("FUSMI_LIB", os.path.join(_HERE, "libfusmi.so"))  # override: experiments only
 
 FUS_F32, FUS_F64 = 0, 1
 FUS_HOST, FUS_DEVICE = 0, 1

@@ -48,7 +48,7 @@ int fus_version(void);
 int fus_init(int device, fus_ctx** ctx);
 int fus_finalize(fus_ctx* ctx);
 int fus_synchronize(fus_ctx* ctx);
-/* Tunables, set before fus_op_create: "block_elems" (elements per LDS block, default 64),
+/* Tunables, set before fus_op_create: "block_elems" (elements per LDS block, default 32),
  * "waves" (waves per workgroup, default 4).  Unknown keys -> FUS_ERR_ARG. */
 int fus_set_option(fus_ctx* ctx, const char* key, int64_t value);
 

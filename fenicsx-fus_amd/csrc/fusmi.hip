@@ -74,6 +74,7 @@ struct fus_ctx
   std::map<std::string, Prof> profs;
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
+  bool local_group = false;  // in-process transport (single-GPU rehearsal of the multi-rank path)
 };
 
 struct Neigh
@@ -124,6 +125,7 @@ struct fus_model
   void *d_bsrc = nullptr, *d_babs = nullptr;
   std::vector<void*> allocs;
   bool initialised = false;
+  bool setup_done = false;
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -227,30 +229,51 @@ static int apply_internal(fus_op* op, const T* coef, const T* x, T* bvec)
   return FUS_OK;
 }
 
+// Shared-DOF exchange of a partial-sum vector (replaces b->scatter_rev(std::plus) +
+// the two scatter_fwd of Linear.hpp:196-206): every sharer ends with the identical total because
+// each adds the partials in ascending rank order.  Three phases so that the transport can sit
+// between them: pack (own partials -> send buffers), exchange (RCCL send/recv over xGMI, or
+// device copies for the in-process transport), unpack (ordered sum).
 template <typename T>
-static int halo_sum(fus_op* op, T* vec)
+static int halo_pack(fus_op* op, const T* vec)
+{
+  if (op->neigh.empty())
+    return FUS_OK;
+  hipStream_t st = op->ctx->stream;
+  for (auto& nb : op->neigh)
+    hipLaunchKernelGGL((k_pack<T>), dim3(nblk(nb.count)), dim3(256), 0, st, nb.count, nb.d_idx, vec,
+                       static_cast<T*>(nb.d_send));
+  hipLaunchKernelGGL((k_pack<T>), dim3(nblk(op->n_uidx)), dim3(256), 0, st, op->n_uidx, op->d_uidx,
+                     vec, static_cast<T*>(op->d_own));
+  HIPCHK(hipGetLastError());
+  return FUS_OK;
+}
+
+static int halo_exchange_rccl(fus_op* op)
 {
   fus_ctx* c = op->ctx;
   if (op->neigh.empty())
     return FUS_OK;
   if (!c->comm)
     return fail(FUS_ERR_STATE, "neighbours set but fus_comm_init was not called");
-  ProfScope ps(c, "halo");
-  hipStream_t st = c->stream;
-  const ncclDataType_t dt = sizeof(T) == 8 ? ncclDouble : ncclFloat;
-  for (auto& nb : op->neigh)
-    hipLaunchKernelGGL((k_pack<T>), dim3(nblk(nb.count)), dim3(256), 0, st, nb.count, nb.d_idx, vec,
-                       static_cast<T*>(nb.d_send));
-  hipLaunchKernelGGL((k_pack<T>), dim3(nblk(op->n_uidx)), dim3(256), 0, st, op->n_uidx, op->d_uidx,
-                     vec, static_cast<T*>(op->d_own));
+  const ncclDataType_t dt = op->ts == 8 ? ncclDouble : ncclFloat;
   NCCLCHK(ncclGroupStart());
   for (auto& nb : op->neigh)
   {
-    NCCLCHK(ncclSend(nb.d_send, nb.count, dt, nb.rank, c->comm, st));
-    NCCLCHK(ncclRecv(nb.d_recv, nb.count, dt, nb.rank, c->comm, st));
+    NCCLCHK(ncclSend(nb.d_send, nb.count, dt, nb.rank, c->comm, c->stream));
+    NCCLCHK(ncclRecv(nb.d_recv, nb.count, dt, nb.rank, c->comm, c->stream));
   }
   NCCLCHK(ncclGroupEnd());
-  // every sharer sums the partials in ascending rank order -> identical bits on all ranks
+  return FUS_OK;
+}
+
+template <typename T>
+static int halo_unpack(fus_op* op, T* vec)
+{
+  fus_ctx* c = op->ctx;
+  if (op->neigh.empty())
+    return FUS_OK;
+  hipStream_t st = c->stream;
   hipLaunchKernelGGL((k_zero_at<T>), dim3(nblk(op->n_uidx)), dim3(256), 0, st, op->n_uidx,
                      op->d_uidx, vec);
   bool own_added = false;
@@ -269,6 +292,46 @@ static int halo_sum(fus_op* op, T* vec)
     hipLaunchKernelGGL((k_add_at<T>), dim3(nblk(op->n_uidx)), dim3(256), 0, st, op->n_uidx,
                        op->d_uidx, static_cast<const T*>(op->d_own), vec);
   HIPCHK(hipGetLastError());
+  return FUS_OK;
+}
+
+// RCCL transport: the three phases back to back on the compute stream
+template <typename T>
+static int halo_sum(fus_op* op, T* vec)
+{
+  if (op->neigh.empty())
+    return FUS_OK;
+  if (op->ctx->local_group)
+    return fail(FUS_ERR_STATE, "in-process transport: use the fus_group_* entry points");
+  ProfScope ps(op->ctx, "halo");
+  FUSCHK(halo_pack<T>(op, vec));
+  FUSCHK(halo_exchange_rccl(op));
+  return halo_unpack<T>(op, vec);
+}
+
+// In-process transport: after every member has packed, move each send buffer to the matching
+// receive buffer of the peer op (device copy), then every member unpacks.
+static int halo_exchange_local(fus_op** ops, int n)
+{
+  for (int i = 0; i < n; ++i)
+    HIPCHK(hipStreamSynchronize(ops[i]->ctx->stream));
+  for (int i = 0; i < n; ++i)
+    for (auto& nb : ops[i]->neigh)
+    {
+      fus_op* peer = nullptr;
+      for (int j = 0; j < n; ++j)
+        if (ops[j]->ctx->rank == nb.rank)
+          peer = ops[j];
+      if (!peer)
+        return fail(FUS_ERR_STATE, "neighbour rank not in the local group");
+      Neigh* back = nullptr;
+      for (auto& pn : peer->neigh)
+        if (pn.rank == ops[i]->ctx->rank)
+          back = &pn;
+      if (!back || back->count != nb.count)
+        return fail(FUS_ERR_STATE, "asymmetric neighbour lists");
+      HIPCHK(hipMemcpy(back->d_recv, nb.d_send, nb.count * ops[i]->ts, hipMemcpyDeviceToDevice));
+    }
   return FUS_OK;
 }
 
@@ -489,16 +552,14 @@ static int model_setup(fus_model* m, const void* c0_, const void* rho0_, int64_t
   FUSCHK(upload(pool, &d_mcoef, mcoef, st));
   m->coef = d_coef;
 
-  // lumped mass: m = M(1/(rho c^2)) 1  (Linear.hpp:127-134) + sum over sharers (scatter_rev :134)
+  // lumped mass, this rank's cells only: m = M(1/(rho c^2)) 1  (Linear.hpp:127-133)
   T* ones = static_cast<T*>(m->un);
   hipLaunchKernelGGL((k_fill<T>), dim3(1024), dim3(256), 0, st, n, ones, T(1));
   FUSCHK((apply_internal<T, P, OP_MASS>(op, d_mcoef, ones, static_cast<T*>(m->m))));
-  FUSCHK(halo_sum<T>(op, static_cast<T*>(m->m)));
-  hipLaunchKernelGGL((k_reciprocal<T>), dim3(nblk(n)), dim3(256), 0, st, n,
-                     static_cast<const T*>(m->m), static_cast<T*>(m->minv));
   HIPCHK(hipMemsetAsync(m->un, 0, n * sizeof(T), st));
 
-  // boundary weights: tag 1 -> (1/rho) w_f, tag 2 -> (1/(rho c)) w_f (forms.py:38-39)
+  // boundary weights of this rank's facets: tag 1 -> (1/rho) w_f, tag 2 -> (1/(rho c)) w_f
+  // (forms.py:38-39), as full internal vectors until the sharers' parts have been added
   std::vector<T> src(op->ndofs, T(0)), absb(op->ndofs, T(0)), cs(op->ncells), ca(op->ncells);
   for (int64_t k = 0; k < op->ncells; ++k)
     cs[k] = T(1.0) / rho0[k], ca[k] = T(1.0) / rho0[k] / c0[k];
@@ -514,51 +575,66 @@ static int model_setup(fus_model* m, const void* c0_, const void* rho0_, int64_t
   }
   facet_diag_host<T>(op, (int64_t)c1.size(), c1.data(), l1.data(), cs.data(), src.data());
   facet_diag_host<T>(op, (int64_t)c2.size(), c2.data(), l2.data(), ca.data(), absb.data());
-  if (!op->neigh.empty())
+  T* tmpc = static_cast<T*>(op->d_tmp_c);
+  void* dst[2] = {m->u_, m->v_};  // scratch until fus_model_init: full-length src / abs weights
+  std::vector<T>* hv[2] = {&src, &absb};
+  for (int k = 0; k < 2; ++k)
   {
-    // facet contributions to interface dofs are summed over the sharing ranks like m
-    T* tmpc = static_cast<T*>(op->d_tmp_c);
-    T* tmpi = static_cast<T*>(op->d_tmp_x);
-    for (std::vector<T>* vec : {&src, &absb})
-    {
-      HIPCHK(hipMemcpyAsync(tmpc, vec->data(), op->ndofs * sizeof(T), hipMemcpyHostToDevice, st));
-      HIPCHK(hipMemsetAsync(tmpi, 0, n * sizeof(T), st));
-      hipLaunchKernelGGL((k_to_internal<T>), dim3(nblk(op->ndofs)), dim3(256), 0, st, op->ndofs,
-                         op->d_dof_perm, tmpc, tmpi);
-      FUSCHK(halo_sum<T>(op, tmpi));
-      hipLaunchKernelGGL((k_from_internal<T, 0>), dim3(nblk(op->ndofs)), dim3(256), 0, st,
-                         op->ndofs, op->d_dof_perm, tmpi, tmpc);
-      HIPCHK(hipMemcpyAsync(vec->data(), tmpc, op->ndofs * sizeof(T), hipMemcpyDeviceToHost, st));
-      HIPCHK(hipStreamSynchronize(st));
-    }
+    HIPCHK(hipMemcpyAsync(tmpc, hv[k]->data(), op->ndofs * sizeof(T), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((k_to_internal<T>), dim3(nblk(op->ndofs)), dim3(256), 0, st, op->ndofs,
+                       op->d_dof_perm, tmpc, static_cast<T*>(dst[k]));
+    HIPCHK(hipStreamSynchronize(st));
   }
-  std::vector<int32_t> bidx;
-  std::vector<T> bsrc, babs;
-  for (int64_t g = 0; g < op->ndofs; ++g)
-    if (src[g] != T(0) || absb[g] != T(0))
-    {
-      bidx.push_back(L.dof_perm[g]);
-      bsrc.push_back(src[g]);
-      babs.push_back(absb[g]);
-    }
-  m->nb = (int64_t)bidx.size();
-  T *d_bsrc, *d_babs;
-  FUSCHK(upload(pool, &m->d_bidx, bidx, st));
-  FUSCHK(upload(pool, &d_bsrc, bsrc, st));
-  FUSCHK(upload(pool, &d_babs, babs, st));
-  m->d_bsrc = d_bsrc, m->d_babs = d_babs;
-  HIPCHK(hipStreamSynchronize(st));
   return FUS_OK;
 }
 
-// One classical RK4 step (Linear.hpp:273-295), state in (u0, v0) on entry and exit.
-template <typename T, int P>
-static int model_step(fus_model* m, double t_, double dt_)
+// Setup vectors that need the sharers' contributions (m.scatter_rev(+), Linear.hpp:134, and the
+// facet integrals of cells owned by other ranks): m, src weights (in u_), abs weights (in v_)
+static void* setup_halo_vector(fus_model* m, int k) { return k == 0 ? m->m : (k == 1 ? m->u_ : m->v_); }
+
+template <typename T>
+static int model_setup_finish(fus_model* m)
 {
   fus_op* op = m->op;
-  fus_ctx* c = m->ctx;
-  hipStream_t st = c->stream;
+  hipStream_t st = m->ctx->stream;
   const int64_t n = op->L.n_internal;
+  hipLaunchKernelGGL((k_reciprocal<T>), dim3(nblk(n)), dim3(256), 0, st, n,
+                     static_cast<const T*>(m->m), static_cast<T*>(m->minv));
+  std::vector<T> src(n), absb(n);
+  HIPCHK(hipMemcpyAsync(src.data(), m->u_, n * sizeof(T), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipMemcpyAsync(absb.data(), m->v_, n * sizeof(T), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  std::vector<int32_t> bidx;
+  std::vector<T> bsrc, babs;
+  for (int64_t i = 0; i < n; ++i)
+    if (src[i] != T(0) || absb[i] != T(0))
+    {
+      bidx.push_back((int32_t)i);
+      bsrc.push_back(src[i]);
+      babs.push_back(absb[i]);
+    }
+  m->nb = (int64_t)bidx.size();
+  T *d_bsrc, *d_babs;
+  FUSCHK(upload(m->allocs, &m->d_bidx, bidx, st));
+  FUSCHK(upload(m->allocs, &d_bsrc, bsrc, st));
+  FUSCHK(upload(m->allocs, &d_babs, babs, st));
+  m->d_bsrc = d_bsrc, m->d_babs = d_babs;
+  HIPCHK(hipMemsetAsync(m->u_, 0, n * sizeof(T), st));
+  HIPCHK(hipMemsetAsync(m->v_, 0, n * sizeof(T), st));
+  HIPCHK(hipStreamSynchronize(st));
+  m->setup_done = true;
+  return FUS_OK;
+}
+
+struct StageScalars
+{
+  double gval, adt, bdt;
+};
+
+// source scalar g(t_n) (Linear.hpp:185-192) and the stage's axpy factors (:282-294), in T
+template <typename T>
+static StageScalars stage_scalars(const fus_model* m, int i, double t_, double dt_)
+{
   const T t = (T)t_, dt = (T)dt_;
   const T a_runge[5] = {0.0, 0.5, 0.5, 1.0, 0.0};
   const T b_runge[4] = {(T)(1.0 / 6.0), (T)(1.0 / 3.0), (T)(1.0 / 3.0), (T)(1.0 / 6.0)};
@@ -566,52 +642,89 @@ static int model_step(fus_model* m, double t_, double dt_)
   const T freq = (T)m->freq, p0 = (T)m->amp, s0 = (T)m->speed;
   const T w0 = (T)(2 * M_PI * m->freq);
   const T period = (T)(1.0 / m->freq), window_length = (T)4.0;
+  const T tn = t + c_runge[i] * dt;
+  T window;
+  if (tn < period * window_length)
+    window = (T)(0.5 * (1.0 - std::cos((double)(freq * (T)M_PI * tn / window_length))));
+  else
+    window = 1.0;
+  StageScalars sc;
+  sc.gval = (double)(window * p0 * w0 / s0 * (T)std::cos((double)(w0 * tn)));
+  sc.adt = (double)(dt * a_runge[i + 1]);
+  sc.bdt = (double)(dt * b_runge[i]);
+  return sc;
+}
+
+// Stage i, first half: b = K(-1/rho) u_stage (this rank's cells), interface partials packed.
+template <typename T, int P>
+static int stage_begin(fus_model* m, int i)
+{
+  fus_op* op = m->op;
+  const T* ustage = static_cast<const T*>(i == 0 ? m->u0 : m->un);  // a_0 = 0: un == u0
+  T* b = static_cast<T*>(m->b);
+  FUSCHK((apply_internal<T, P, OP_STIFFNESS>(op, static_cast<const T*>(m->coef), ustage, b)));
+  return halo_pack<T>(op, b);
+}
+
+// Stage i, second half: ordered sum of the sharers' partials, boundary terms, fused update.
+template <typename T>
+static int stage_end(fus_model* m, int i, double t, double dt)
+{
+  fus_op* op = m->op;
+  fus_ctx* c = m->ctx;
+  hipStream_t st = c->stream;
+  const int64_t n = op->L.n_internal;
+  const StageScalars sc = stage_scalars<T>(m, i, t, dt);
   T *u0 = static_cast<T*>(m->u0), *v0 = static_cast<T*>(m->v0), *u_ = static_cast<T*>(m->u_),
     *v_ = static_cast<T*>(m->v_), *un = static_cast<T*>(m->un), *vn = static_cast<T*>(m->vn),
     *b = static_cast<T*>(m->b);
   const T* minv = static_cast<const T*>(m->minv);
-  const unsigned grid = (unsigned)std::min<int64_t>(nblk(n / (16 / sizeof(T))), 256 * 16);
-  for (int i = 0; i < 4; ++i)
+  FUSCHK(halo_unpack<T>(op, b));
+  if (m->nb > 0)
   {
-    const T tn = t + c_runge[i] * dt;
-    // source scalar (Linear.hpp:185-192)
-    T window;
-    if (tn < period * window_length)
-      window = (T)(0.5 * (1.0 - std::cos((double)(freq * (T)M_PI * tn / window_length))));
-    else
-      window = 1.0;
-    const T gval = window * p0 * w0 / s0 * (T)std::cos((double)(w0 * tn));
-    const T* ustage = (i == 0) ? u0 : un;  // a_0 = 0: un == u0, vn == v0
-    T* vstage = (i == 0) ? v0 : vn;
-    FUSCHK((apply_internal<T, P, OP_STIFFNESS>(op, static_cast<const T*>(m->coef), ustage, b)));
-    FUSCHK(halo_sum<T>(op, b));
-    if (m->nb > 0)
+    ProfScope ps(c, "boundary");
+    hipLaunchKernelGGL((k_boundary<T>), dim3(nblk(m->nb)), dim3(256), 0, st, m->nb, m->d_bidx,
+                       static_cast<const T*>(m->d_bsrc), static_cast<const T*>(m->d_babs),
+                       (T)sc.gval, (i == 0) ? v0 : vn, b);
+  }
+  {
+    ProfScope ps(c, "stage");
+    const unsigned grid = (unsigned)std::min<int64_t>(nblk(n / (16 / sizeof(T))), 256 * 16);
+    const T adt = (T)sc.adt, bdt = (T)sc.bdt;
+    switch (i)
     {
-      ProfScope ps(c, "boundary");
-      hipLaunchKernelGGL((k_boundary<T>), dim3(nblk(m->nb)), dim3(256), 0, st, m->nb, m->d_bidx,
-                         static_cast<const T*>(m->d_bsrc), static_cast<const T*>(m->d_babs), gval,
-                         vstage, b);
-    }
-    {
-      ProfScope ps(c, "stage");
-      const T adt = dt * a_runge[i + 1], bdt = dt * b_runge[i];
-      switch (i)
-      {
-      case 0:
-        hipLaunchKernelGGL((k_stage<T, 0>), dim3(grid), dim3(256), 0, st, n, b, minv, vn, un, u0,
-                           v0, u_, v_, adt, bdt);
-        break;
-      case 3:
-        hipLaunchKernelGGL((k_stage<T, 3>), dim3(grid), dim3(256), 0, st, n, b, minv, vn, un, u0,
-                           v0, u_, v_, adt, bdt);
-        break;
-      default:
-        hipLaunchKernelGGL((k_stage<T, 1>), dim3(grid), dim3(256), 0, st, n, b, minv, vn, un, u0,
-                           v0, u_, v_, adt, bdt);
-      }
+    case 0:
+      hipLaunchKernelGGL((k_stage<T, 0>), dim3(grid), dim3(256), 0, st, n, b, minv, vn, un, u0, v0,
+                         u_, v_, adt, bdt);
+      break;
+    case 3:
+      hipLaunchKernelGGL((k_stage<T, 3>), dim3(grid), dim3(256), 0, st, n, b, minv, vn, un, u0, v0,
+                         u_, v_, adt, bdt);
+      break;
+    default:
+      hipLaunchKernelGGL((k_stage<T, 1>), dim3(grid), dim3(256), 0, st, n, b, minv, vn, un, u0, v0,
+                         u_, v_, adt, bdt);
     }
   }
   HIPCHK(hipGetLastError());
+  return FUS_OK;
+}
+
+// One classical RK4 step (Linear.hpp:273-295), state in (u0, v0) on entry and exit; RCCL (or
+// single-rank) transport.
+template <typename T, int P>
+static int model_step(fus_model* m, double t, double dt)
+{
+  for (int i = 0; i < 4; ++i)
+  {
+    FUSCHK((stage_begin<T, P>(m, i)));
+    if (!m->op->neigh.empty())
+    {
+      ProfScope ps(m->ctx, "halo");
+      FUSCHK(halo_exchange_rccl(m->op));
+    }
+    FUSCHK(stage_end<T>(m, i, t, dt));
+  }
   return FUS_OK;
 }
 
@@ -695,6 +808,33 @@ static int d_model_setup(fus_model* m, const void* c0, const void* rho0, int64_t
 static int d_model_step(fus_model* m, double t, double dt)
 {
   FUS_DISPATCH(m->op->dtype, m->op->P, (model_step<TT, PP>(m, t, dt)));
+}
+static int d_stage_begin(fus_model* m, int i)
+{
+  FUS_DISPATCH(m->op->dtype, m->op->P, (stage_begin<TT, PP>(m, i)));
+}
+static int d_stage_end(fus_model* m, int i, double t, double dt)
+{
+  return m->op->dtype == FUS_F64 ? stage_end<double>(m, i, t, dt) : stage_end<float>(m, i, t, dt);
+}
+static int d_setup_finish(fus_model* m)
+{
+  return m->op->dtype == FUS_F64 ? model_setup_finish<double>(m) : model_setup_finish<float>(m);
+}
+static int d_halo_sum(fus_op* op, void* v)
+{
+  return op->dtype == FUS_F64 ? halo_sum<double>(op, static_cast<double*>(v))
+                              : halo_sum<float>(op, static_cast<float*>(v));
+}
+static int d_halo_pack(fus_op* op, const void* v)
+{
+  return op->dtype == FUS_F64 ? halo_pack<double>(op, static_cast<const double*>(v))
+                              : halo_pack<float>(op, static_cast<const float*>(v));
+}
+static int d_halo_unpack(fus_op* op, void* v)
+{
+  return op->dtype == FUS_F64 ? halo_unpack<double>(op, static_cast<double*>(v))
+                              : halo_unpack<float>(op, static_cast<float*>(v));
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1019,6 +1159,15 @@ int fus_model_create(fus_ctx* c, int kind, fus_op* op, const void* c0, const voi
   std::unique_ptr<fus_model> m(new fus_model());
   m->ctx = c, m->op = op, m->kind = kind, m->freq = freq, m->amp = amp, m->speed = speed;
   int r = d_model_setup(m.get(), c0, rho0, nfacets, facet_cells, facet_local, facet_tags);
+  if (r == FUS_OK && !c->local_group)
+  {
+    // add the sharers' parts of m / src / abs over RCCL, then finish; with the in-process
+    // transport this happens in fus_group_finish_setup once every member exists
+    for (int k = 0; k < 3 && r == FUS_OK; ++k)
+      r = d_halo_sum(op, setup_halo_vector(m.get(), k));
+    if (r == FUS_OK)
+      r = d_setup_finish(m.get());
+  }
   if (r != FUS_OK)
   {
     for (void* q : m->allocs)
@@ -1026,6 +1175,75 @@ int fus_model_create(fus_ctx* c, int kind, fus_op* op, const void* c0, const voi
     return r;
   }
   *out = m.release();
+  return FUS_OK;
+}
+
+// ---- in-process transport (single-GPU rehearsal of the multi-rank path) -----------------------
+int fus_comm_init_local(fus_ctx** ctxs, int n)
+{
+  if (!ctxs || n < 1)
+    return fail(FUS_ERR_ARG, "bad group");
+  for (int i = 0; i < n; ++i)
+  {
+    if (!ctxs[i])
+      return fail(FUS_ERR_ARG, "null ctx in group");
+    ctxs[i]->rank = i, ctxs[i]->nranks = n, ctxs[i]->local_group = n > 1;
+  }
+  return FUS_OK;
+}
+
+static int group_halo(fus_model** ms, int n, int which_setup_vec)
+{
+  std::vector<fus_op*> ops(n);
+  for (int i = 0; i < n; ++i)
+  {
+    ops[i] = ms[i]->op;
+    void* v = which_setup_vec >= 0 ? setup_halo_vector(ms[i], which_setup_vec) : ms[i]->b;
+    FUSCHK(d_halo_pack(ops[i], v));
+  }
+  FUSCHK(halo_exchange_local(ops.data(), n));
+  if (which_setup_vec >= 0)
+    for (int i = 0; i < n; ++i)
+      FUSCHK(d_halo_unpack(ops[i], setup_halo_vector(ms[i], which_setup_vec)));
+  return FUS_OK;
+}
+
+int fus_group_finish_setup(fus_model** ms, int n)
+{
+  if (!ms || n < 1)
+    return fail(FUS_ERR_ARG, "bad group");
+  for (int k = 0; k < 3; ++k)
+    FUSCHK(group_halo(ms, n, k));
+  for (int i = 0; i < n; ++i)
+    FUSCHK(d_setup_finish(ms[i]));
+  return FUS_OK;
+}
+
+int fus_group_rk4_steps(fus_model** ms, int n, double t0, double dt, int64_t nsteps)
+{
+  if (!ms || n < 1)
+    return fail(FUS_ERR_ARG, "bad group");
+  for (int i = 0; i < n; ++i)
+    if (!ms[i]->setup_done || !ms[i]->initialised)
+      return fail(FUS_ERR_STATE, "group member not set up / initialised");
+  double t = t0;
+  for (int64_t s = 0; s < nsteps; ++s)
+  {
+    for (int st = 0; st < 4; ++st)
+    {
+      for (int i = 0; i < n; ++i)
+        FUSCHK(d_stage_begin(ms[i], st));   // includes the pack
+      std::vector<fus_op*> ops(n);
+      for (int i = 0; i < n; ++i)
+        ops[i] = ms[i]->op;
+      FUSCHK(halo_exchange_local(ops.data(), n));
+      for (int i = 0; i < n; ++i)
+        FUSCHK(d_stage_end(ms[i], st, t, dt));
+    }
+    t += dt;
+  }
+  for (int i = 0; i < n; ++i)
+    HIPCHK(hipStreamSynchronize(ms[i]->ctx->stream));
   return FUS_OK;
 }
 
@@ -1057,10 +1275,12 @@ int fus_model_rk4(fus_model* m, double t0, double tf_, double dt_, int64_t* nste
 {
   if (!m)
     return fail(FUS_ERR_ARG, "null model");
-  if (!m->initialised)
+  if (!m->initialised || !m->setup_done)
     return fail(FUS_ERR_STATE, "fus_model_init (or fus_model_set) must be called before rk4");
   if (!(dt_ > 0))
     return fail(FUS_ERR_ARG, "dt must be positive");
+  if (m->ctx->local_group)
+    return fail(FUS_ERR_STATE, "in-process transport: use fus_group_rk4_steps");
   HIPCHK(hipSetDevice(m->ctx->device));
   int64_t step = 0;
   if (m->op->dtype == FUS_F64)
@@ -1095,8 +1315,10 @@ int fus_model_rk4_steps(fus_model* m, double t0, double dt, int64_t nsteps)
 {
   if (!m)
     return fail(FUS_ERR_ARG, "null model");
-  if (!m->initialised)
+  if (!m->initialised || !m->setup_done)
     return fail(FUS_ERR_STATE, "fus_model_init (or fus_model_set) must be called before rk4");
+  if (m->ctx->local_group)
+    return fail(FUS_ERR_STATE, "in-process transport: use fus_group_rk4_steps");
   HIPCHK(hipSetDevice(m->ctx->device));
   double t = t0;
   for (int64_t s = 0; s < nsteps; ++s)

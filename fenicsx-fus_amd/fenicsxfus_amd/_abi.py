@@ -22,7 +22,8 @@ SYMBOLS = [
     "fus_mass_apply", "fus_op_get_geometry", "fus_op_get_tables", "fus_op_info", "fus_facet_diag",
     "fus_op_set_neighbours", "fus_model_create", "fus_model_destroy", "fus_model_init", "fus_model_rk4",
     "fus_model_rk4_steps", "fus_model_get", "fus_model_set", "fus_model_get_mass", "fus_model_ndofs",
-    "fus_profile_enable", "fus_profile_get", "fus_layout_check",
+    "fus_profile_enable", "fus_profile_get", "fus_layout_check", "fus_comm_init_local",
+    "fus_group_finish_setup", "fus_group_rk4_steps",
 ]
 
 
@@ -93,6 +94,14 @@ class Context:
         buf = (C.c_char * 128)()
         check(lib().fus_comm_unique_id(buf))
         return bytes(buf)
+
+    @staticmethod
+    def init_local_group(ctxs):
+        """In-process transport: these contexts (one GPU) act as ranks 0..n-1 (tests only)."""
+        arr = (C.c_void_p * len(ctxs))(*[c.h for c in ctxs])
+        check(lib().fus_comm_init_local(arr, C.c_int(len(ctxs))))
+        for i, c in enumerate(ctxs):
+            c.rank, c.nranks = i, len(ctxs)
 
     def profile_enable(self, on: bool = True):
         check(lib().fus_profile_enable(self.h, C.c_int(int(on))))

@@ -97,3 +97,15 @@ class LinearSpectralExplicit:
         if self.h:
             lib().fus_model_destroy(self.h)
             self.h = C.c_void_p()
+
+
+def group_finish_setup(models):
+    """In-process transport: add the sharers' parts of the mass / boundary vectors (tests)."""
+    arr = (C.c_void_p * len(models))(*[m.h for m in models])
+    check(lib().fus_group_finish_setup(arr, C.c_int(len(models))))
+
+
+def group_rk4_steps(models, t0: float, dt: float, nsteps: int):
+    """In-process transport: advance all slab models in lock-step (tests)."""
+    arr = (C.c_void_p * len(models))(*[m.h for m in models])
+    check(lib().fus_group_rk4_steps(arr, C.c_int(len(models)), C.c_double(t0), C.c_double(dt), C.c_int64(nsteps)))

@@ -58,6 +58,12 @@ int fus_set_option(fus_ctx* ctx, const char* key, int64_t value);
 int fus_comm_unique_id(void* id128);
 int fus_comm_init(fus_ctx* ctx, int rank, int nranks, const void* id128);
 
+/* In-process transport for rehearsing the multi-rank path on ONE GPU (tests): the n contexts of
+ * this process become ranks 0..n-1 and interface planes move by device copies instead of RCCL.
+ * Models of such contexts are finished with fus_group_finish_setup (the sharers' parts of m and
+ * of the boundary weights) and advanced in lock-step with fus_group_rk4_steps. */
+int fus_comm_init_local(fus_ctx** ctxs, int n);
+
 /* ---- operator data ------------------------------------------------------------------------
  * Replaces the constructors StiffnessSpectral3D<T,P>(V) / MassSpectral3D<T,P>(V)
  * (cpp/fenicsx-sf/common/spectral_op.hpp:135-171, :32-63): takes the tensor-ordered cell dofmap
@@ -139,6 +145,9 @@ int fus_model_set(fus_model* model, int which, const void* in, int space);
 /* Lumped mass vector m in caller numbering (host T[ndofs]); parity inspection. */
 int fus_model_get_mass(fus_model* model, void* out);
 int64_t fus_model_ndofs(fus_model* model); /* number_of_dofs(), Linear.hpp:318 (local) */
+
+int fus_group_finish_setup(fus_model** models, int n);
+int fus_group_rk4_steps(fus_model** models, int n, double t0, double dt, int64_t nsteps);
 
 /* ---- measurement -----------------------------------------------------------------------------
  * HIP-event timing of the library's own kernels on the stream they run on.  Names:

@@ -1,0 +1,170 @@
+"""Multi-rank (x-slab) path: shared-DOF partial sums exchanged per stage, identical state on all
+sharers.  (1) CPU, world_size 2 over gloo: the partition data (slab meshes, interface planes,
+exterior-facet tags) and the exchange algorithm, with the oracle as the per-rank operator, against
+the single-rank oracle.  (2) GPU: the library's own pack / ordered-sum / stage kernels with the
+in-process transport (all slabs on one MI355X), against the single-rank oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import fenicsxfus_amd as fa
+from util import Problem
+
+P, N_GLOBAL, HI = 4, (6, 3, 3), [0.024, 0.012, 0.012]
+F0, P0, S0 = 0.5e6, 60000.0, 1500.0
+NSTEPS = 6
+
+
+def material(mesh):
+    nc = mesh.num_cells
+    c, rho = np.full(nc, 1500.0), np.full(nc, 1000.0)
+    cx = mesh.cell_centroids()[:, 0]
+    sel = (cx > 0.4 * HI[0]) & (cx < 0.6 * HI[0])   # bone slab straddling the 2-rank interface
+    c[sel], rho[sel] = 2800.0, 1850.0
+    return c, rho
+
+
+def dt_value():
+    return 0.5 * (HI[0] / N_GLOBAL[0]) / (2800.0 * P**2)
+
+
+def single_rank_reference(orc):
+    pr = Problem(orc, N_GLOBAL, P, hi=HI, perturb=0.1)
+    c, rho = material(pr.mesh)
+    tags = fa.tag_box_boundary(pr.mesh)
+    m, src, absb, coeff = pr.linear_model_vectors(c, rho, tags)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    dt = dt_value()
+    # tf a hair past NSTEPS*dt: NSTEPS full steps (+ a ~1e-12*dt remainder step, far below tolerance)
+    orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, F0, P0, S0, 0.0, NSTEPS * dt * (1 + 1e-12), dt, u, v)
+    return pr, m, u, v
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _exchange_sum(dist, rank, V, vec):
+    """Every sharer adds the partials of an interface plane in ascending rank order."""
+    import torch
+
+    out = vec.copy()
+    recv = {}
+    for nb, idx in V.neighbours:
+        send = torch.from_numpy(vec[idx].copy())
+        buf = torch.empty_like(send)
+        if rank < nb:
+            dist.send(send, nb), dist.recv(buf, nb)
+        else:
+            dist.recv(buf, nb), dist.send(send, nb)
+        recv[nb] = (idx, buf.numpy())
+    for nb, (idx, buf) in recv.items():
+        out[idx] = (buf + vec[idx]) if nb < rank else (vec[idx] + buf)
+    return out
+
+
+def _gloo_worker(rank, size, port, q):
+    import torch.distributed as dist
+
+    import oracle as orc
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    pr = Problem(orc, N_GLOBAL, P, hi=HI, perturb=0.1, rank=rank, size=size)
+    c, rho = material(pr.mesh)
+    tags = fa.tag_box_boundary(pr.mesh)
+    m, src, absb, coeff = pr.linear_model_vectors(c, rho, tags)
+    m, src, absb = (_exchange_sum(dist, rank, pr.V, a) for a in (m, src, absb))
+    # host restatement of the library's stage loop (fusmi.hip stage_begin / stage_end)
+    n = pr.ndofs
+    u0, v0 = np.zeros(n), np.zeros(n)
+    u_, v_, un, vn = (np.zeros(n) for _ in range(4))
+    dt, t = dt_value(), 0.0
+    a_r, b_r, c_r = [0, .5, .5, 1, 0], [1 / 6, 1 / 3, 1 / 3, 1 / 6], [0, .5, .5, 1]
+    for _ in range(NSTEPS):
+        for i in range(4):
+            us, vs = (u0, v0) if i == 0 else (un, vn)
+            b = _exchange_sum(dist, rank, pr.V, pr.K(us, coeff))
+            tn = t + c_r[i] * dt
+            win = 0.5 * (1 - np.cos(F0 * np.pi * tn / 4.0)) if tn < 4.0 / F0 else 1.0
+            g = win * P0 * 2 * np.pi * F0 / S0 * np.cos(2 * np.pi * F0 * tn)
+            b = b + g * src - absb * vs
+            kv = b / m
+            adt, bdt = dt * a_r[i + 1], dt * b_r[i]
+            if i == 0:
+                u_, v_, un, vn = v0 * bdt + u0, kv * bdt + v0, v0 * adt + u0, kv * adt + v0
+            elif i == 3:
+                u0, v0 = vn * bdt + u_, kv * bdt + v_
+            else:
+                u_, v_, un, vn = vn * bdt + u_, kv * bdt + v_, vn * adt + u0, kv * adt + v0
+        t += dt
+    q.put((rank, pr.V.global_offset, m, u0, v0))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_gloo_cpu(orc):
+    import torch.multiprocessing as mp
+
+    ref, m_ref, u_ref, v_ref = single_rank_reference(orc)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = [q.get(timeout=120) for _ in procs]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    planes = {}
+    for rank, off, m, u, v in res:
+        n = len(u)
+        assert np.abs(m - m_ref[off:off + n]).max() < 1e-14 * np.abs(m_ref).max()
+        assert np.abs(u - u_ref[off:off + n]).max() < 1e-10 * np.abs(u_ref).max()
+        assert np.abs(v - v_ref[off:off + n]).max() < 1e-10 * np.abs(v_ref).max()
+        planes[rank] = (off, u)
+    # the shared plane is bit-identical on both sharers
+    off1 = planes[1][0]
+    plane = len(planes[0][1]) - off1
+    assert np.array_equal(planes[0][1][off1:], planes[1][1][:plane])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [2, 3])
+def test_slabs_in_process_gpu(orc, size):
+    ref, m_ref, u_ref, v_ref = single_rank_reference(orc)
+    ctxs = [fa.Context(0) for _ in range(size)]
+    fa.Context.init_local_group(ctxs)
+    models, offs = [], []
+    dt = dt_value()
+    for r in range(size):
+        mesh = fa.BoxMesh([0, 0, 0], HI, N_GLOBAL, rank=r, size=size, perturb=0.1)
+        V = fa.FunctionSpace(mesh, P)
+        c, rho = material(mesh)
+        models.append(fa.LinearSpectralExplicit(mesh, fa.tag_box_boundary(mesh), P, c, rho, F0, P0, S0, 4, dt, V=V,
+                                                ctx=ctxs[r]))
+        offs.append(V.global_offset)
+    fa.group_finish_setup(models)
+    for m in models:
+        m.init()
+    fa.group_rk4_steps(models, 0.0, dt, NSTEPS)
+    us = []
+    for r, mdl in enumerate(models):
+        n = mdl.data.ndofs
+        assert np.abs(mdl.mass_vector() - m_ref[offs[r]:offs[r] + n]).max() < 1e-14 * np.abs(m_ref).max()
+        u = mdl.u_sol().x.array
+        us.append(u)
+        assert np.abs(u - u_ref[offs[r]:offs[r] + n]).max() < 1e-10 * np.abs(u_ref).max()
+        assert np.abs(mdl.v_n.x.array - v_ref[offs[r]:offs[r] + n]).max() < 1e-10 * np.abs(v_ref).max()
+    for r in range(size - 1):       # interface planes bit-identical on both sharers
+        plane = len(us[r]) - (offs[r + 1] - offs[r])
+        assert np.array_equal(us[r][-plane:], us[r + 1][:plane])
+    for mdl in models:
+        mdl.close()
+    for c in ctxs:
+        c.close()

@@ -79,7 +79,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=64, help="cells per axis per GPU")
+    ap.add_argument("--cells", type=int, default=64, help="cells per axis per GPU")
     ap.add_argument("--P", type=int, default=4)
     ap.add_argument("--block-elems", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
@@ -98,6 +98,8 @@ def main():
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    if "FUSMI_BENCH_DEVICE" in os.environ:   # rehearsal of N>1 on a one-GPU box
+        local_rank = int(os.environ["FUSMI_BENCH_DEVICE"])
     torch.cuda.set_device(local_rank)
 
     import fenicsxfus_amd as fa
@@ -118,7 +120,7 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
-    P, n = args.P, args.n
+    P, n = args.P, args.cells
     mesh, V, tags, c0, rho0, freq, p0, dt = workload(n, P, rank, world)
     nc = mesh.num_cells
     model = fa.LinearSpectralExplicit(mesh, tags, P, np.full(nc, c0), np.full(nc, rho0), freq, p0, c0, 4, dt, V=V,

@@ -19,7 +19,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", *SRC,
-           "-o", OUT, "-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
+           "-o", OUT, "-ldl", "-Wl,-rpath,/opt/rocm/lib"]  # RCCL is bound at run time (fusmi.hip rccl_load)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

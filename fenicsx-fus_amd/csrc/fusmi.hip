@@ -6,6 +6,7 @@
 // entry point needs the HIP device and fails with FUS_ERR_HIP without one.
 #include "../../include/fusmi.h"
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
@@ -45,7 +46,7 @@ static int fail(int code, const std::string& msg)
   {                                                                                                \
     ncclResult_t r_ = (expr);                                                                      \
     if (r_ != ncclSuccess)                                                                         \
-      return fail(FUS_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));               \
+      return fail(FUS_ERR_RCCL, std::string(#expr) + ": " + g_rccl.GetErrorString(r_));            \
   } while (0)
 #define FUSCHK(expr)                                                                               \
   do                                                                                               \
@@ -54,6 +55,59 @@ static int fail(int code, const std::string& msg)
     if (r_ != FUS_OK)                                                                              \
       return r_;                                                                                   \
   } while (0)
+
+// -------------------------------------------------------------------------------------------------
+// RCCL, bound at run time.  A host process may already carry an RCCL (PyTorch bundles its own
+// librccl.so); binding to the resident copy instead of linking a second one keeps a single RCCL
+// in the process.  Order: $FUSMI_RCCL (explicit path), an already loaded librccl, the system one.
+// -------------------------------------------------------------------------------------------------
+struct RcclApi
+{
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+static RcclApi g_rccl;
+
+static int rccl_load()
+{
+  if (g_rccl.handle)
+    return FUS_OK;
+  void* h = nullptr;
+  if (const char* path = getenv("FUSMI_RCCL"))
+    h = dlopen(path, RTLD_NOW | RTLD_GLOBAL);
+  for (const char* name : {"librccl.so.1", "librccl.so"})
+    if (!h)
+      h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+    if (!h)
+      h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+  if (!h)
+    return fail(FUS_ERR_RCCL, std::string("cannot load librccl: ") + dlerror());
+  RcclApi a;
+  a.handle = h;
+#define FUS_SYM(field, name)                                                                       \
+  *reinterpret_cast<void**>(&a.field) = dlsym(h, name);                                            \
+  if (!a.field)                                                                                    \
+    return fail(FUS_ERR_RCCL, "librccl lacks " name);
+  FUS_SYM(GetUniqueId, "ncclGetUniqueId")
+  FUS_SYM(CommInitRank, "ncclCommInitRank")
+  FUS_SYM(CommDestroy, "ncclCommDestroy")
+  FUS_SYM(Send, "ncclSend")
+  FUS_SYM(Recv, "ncclRecv")
+  FUS_SYM(GroupStart, "ncclGroupStart")
+  FUS_SYM(GroupEnd, "ncclGroupEnd")
+  FUS_SYM(GetErrorString, "ncclGetErrorString")
+#undef FUS_SYM
+  g_rccl = a;
+  return FUS_OK;
+}
 
 // -------------------------------------------------------------------------------------------------
 // handles
@@ -257,13 +311,13 @@ static int halo_exchange_rccl(fus_op* op)
   if (!c->comm)
     return fail(FUS_ERR_STATE, "neighbours set but fus_comm_init was not called");
   const ncclDataType_t dt = op->ts == 8 ? ncclDouble : ncclFloat;
-  NCCLCHK(ncclGroupStart());
+  NCCLCHK(g_rccl.GroupStart());
   for (auto& nb : op->neigh)
   {
-    NCCLCHK(ncclSend(nb.d_send, nb.count, dt, nb.rank, c->comm, c->stream));
-    NCCLCHK(ncclRecv(nb.d_recv, nb.count, dt, nb.rank, c->comm, c->stream));
+    NCCLCHK(g_rccl.Send(nb.d_send, nb.count, dt, nb.rank, c->comm, c->stream));
+    NCCLCHK(g_rccl.Recv(nb.d_recv, nb.count, dt, nb.rank, c->comm, c->stream));
   }
-  NCCLCHK(ncclGroupEnd());
+  NCCLCHK(g_rccl.GroupEnd());
   return FUS_OK;
 }
 
@@ -874,7 +928,7 @@ int fus_finalize(fus_ctx* c)
     for (auto& ev : kv.second.ev)
       (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
   if (c->comm)
-    ncclCommDestroy(c->comm);
+    g_rccl.CommDestroy(c->comm);
   (void)hipStreamDestroy(c->stream);
   delete c;
   return FUS_OK;
@@ -910,8 +964,9 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
 int fus_comm_unique_id(void* id128)
 {
   static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
+  FUSCHK(rccl_load());
   ncclUniqueId id;
-  NCCLCHK(ncclGetUniqueId(&id));
+  NCCLCHK(g_rccl.GetUniqueId(&id));
   memcpy(id128, &id, 128);
   return FUS_OK;
 }
@@ -923,10 +978,52 @@ int fus_comm_init(fus_ctx* c, int rank, int nranks, const void* id128)
   c->rank = rank, c->nranks = nranks;
   if (nranks == 1)
     return FUS_OK;
+  FUSCHK(rccl_load());
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   HIPCHK(hipSetDevice(c->device));
-  NCCLCHK(ncclCommInitRank(&c->comm, nranks, id, rank));
+  NCCLCHK(g_rccl.CommInitRank(&c->comm, nranks, id, rank));
+  return FUS_OK;
+}
+
+// Round trip of n doubles through ncclSend/ncclRecv to the own rank on the library's stream:
+// checks the run-time RCCL binding and the grouped send/recv pattern the halo exchange uses.
+int fus_comm_selftest(fus_ctx* c, int64_t n)
+{
+  if (!c || n < 1)
+    return fail(FUS_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  FUSCHK(rccl_load());
+  ncclComm_t comm = c->comm;
+  bool own = false;
+  if (!comm)
+  {
+    ncclUniqueId id;
+    NCCLCHK(g_rccl.GetUniqueId(&id));
+    NCCLCHK(g_rccl.CommInitRank(&comm, 1, id, 0));
+    own = true;
+  }
+  std::vector<double> h(n), back(n, 0.0);
+  for (int64_t i = 0; i < n; ++i)
+    h[i] = 0.5 * (double)i - 3.0;
+  double *a = nullptr, *b = nullptr;
+  HIPCHK(hipMalloc((void**)&a, n * sizeof(double)));
+  HIPCHK(hipMalloc((void**)&b, n * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(a, h.data(), n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  HIPCHK(hipMemsetAsync(b, 0, n * sizeof(double), c->stream));
+  const int self = own ? 0 : c->rank;
+  NCCLCHK(g_rccl.GroupStart());
+  NCCLCHK(g_rccl.Send(a, n, ncclDouble, self, comm, c->stream));
+  NCCLCHK(g_rccl.Recv(b, n, ncclDouble, self, comm, c->stream));
+  NCCLCHK(g_rccl.GroupEnd());
+  HIPCHK(hipMemcpyAsync(back.data(), b, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(hipStreamSynchronize(c->stream));
+  (void)hipFree(a), (void)hipFree(b);
+  if (own)
+    g_rccl.CommDestroy(comm);
+  for (int64_t i = 0; i < n; ++i)
+    if (back[i] != h[i])
+      return fail(FUS_ERR_RCCL, "RCCL self send/recv returned wrong data");
   return FUS_OK;
 }
 

@@ -18,7 +18,7 @@ FUS_U, FUS_V = 0, 1
 # every symbol include/fusmi.h declares
 SYMBOLS = [
     "fus_last_error", "fus_version", "fus_init", "fus_finalize", "fus_synchronize", "fus_set_option",
-    "fus_comm_unique_id", "fus_comm_init", "fus_op_create", "fus_op_destroy", "fus_stiffness_apply",
+    "fus_comm_unique_id", "fus_comm_init", "fus_comm_selftest", "fus_op_create", "fus_op_destroy", "fus_stiffness_apply",
     "fus_mass_apply", "fus_op_get_geometry", "fus_op_get_tables", "fus_op_info", "fus_facet_diag",
     "fus_op_set_neighbours", "fus_model_create", "fus_model_destroy", "fus_model_init", "fus_model_rk4",
     "fus_model_rk4_steps", "fus_model_get", "fus_model_set", "fus_model_get_mass", "fus_model_ndofs",
@@ -84,13 +84,30 @@ class Context:
     def synchronize(self):
         check(lib().fus_synchronize(self.h))
 
+    @staticmethod
+    def _prefer_resident_rccl():
+        """If PyTorch (which bundles its own librccl) is loaded, bind to that copy."""
+        import sys
+
+        torch = sys.modules.get("torch")
+        if torch is not None and "FUSMI_RCCL" not in os.environ:
+            cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if os.path.exists(cand):
+                os.environ["FUSMI_RCCL"] = cand
+
     def comm_init(self, rank: int, nranks: int, unique_id: bytes | None):
+        self._prefer_resident_rccl()
         buf = (C.c_char * 128).from_buffer_copy(unique_id) if unique_id else None
         check(lib().fus_comm_init(self.h, C.c_int(rank), C.c_int(nranks), buf))
         self.rank, self.nranks = rank, nranks
 
+    def comm_selftest(self, n: int = 1 << 16):
+        self._prefer_resident_rccl()
+        check(lib().fus_comm_selftest(self.h, C.c_int64(n)))
+
     @staticmethod
     def unique_id() -> bytes:
+        Context._prefer_resident_rccl()
         buf = (C.c_char * 128)()
         check(lib().fus_comm_unique_id(buf))
         return bytes(buf)

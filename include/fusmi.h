@@ -57,6 +57,10 @@ int fus_set_option(fus_ctx* ctx, const char* key, int64_t value);
  * MPI_Init/MPI_COMM_WORLD inside PetscInitialize (BM7-SC1/main.cpp:22). */
 int fus_comm_unique_id(void* id128);
 int fus_comm_init(fus_ctx* ctx, int rank, int nranks, const void* id128);
+/* Diagnostic: n doubles through grouped ncclSend/ncclRecv to the own rank on the library stream
+ * (checks the run-time RCCL binding; RCCL is dlopen'ed, preferring a copy already resident in the
+ * process such as PyTorch's, or $FUSMI_RCCL). */
+int fus_comm_selftest(fus_ctx* ctx, int64_t n);
 
 /* In-process transport for rehearsing the multi-rank path on ONE GPU (tests): the n contexts of
  * this process become ranks 0..n-1 and interface planes move by device copies instead of RCCL.

@@ -168,3 +168,11 @@ def test_slabs_in_process_gpu(orc, size):
         mdl.close()
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.gpu
+def test_rccl_binding_selftest():
+    # grouped ncclSend/ncclRecv (to the own rank) through the dlopen'ed RCCL on the library stream
+    c = fa.Context(0)
+    c.comm_selftest(1 << 18)
+    c.close()

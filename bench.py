@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--P", type=int, default=4)
     ap.add_argument("--block-elems", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
+    ap.add_argument("--deterministic", type=int, default=None, help="1: conflict-free rounds, 0: LDS atomics")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=10)
@@ -104,8 +105,9 @@ def main():
 
     import fenicsxfus_amd as fa
 
-    ctx = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves)
-    if world > 1:
+    ctx = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves, deterministic=args.deterministic)
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run
+    if world > 1 or launched:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -115,7 +117,7 @@ def main():
         ctx.comm_init(rank, world, ids[0])
 
     def barrier():
-        if world > 1:
+        if world > 1 or launched:
             dist.barrier()
         torch.cuda.synchronize()
         ctx.synchronize()
@@ -136,7 +138,7 @@ def main():
     model.rk4_steps(args.warmup * dt, dt, args.steps, sync=False)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or launched:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -190,7 +192,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(P, args.cpu_n, args.cpu_steps)
         print(json.dumps(out))
     model.close()
-    if world > 1:
+    if world > 1 or launched:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -18,7 +18,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", *SRC,
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-munsafe-fp-atomics", *SRC,
            "-o", OUT, "-ldl", "-Wl,-rpath,/opt/rocm/lib"]  # RCCL is bound at run time (fusmi.hip rccl_load)
     if verbose:
         print(" ".join(cmd))

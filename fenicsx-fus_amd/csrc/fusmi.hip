@@ -123,6 +123,7 @@ struct fus_ctx
 {
   int device = 0;
   hipStream_t stream = nullptr;
+  int deterministic = 0;  // 1: conflict-free rounds (bitwise reproducible); 0: LDS atomics
   int block_elems = 32, waves = 4;  // measured best on MI355X at p=4 fp64 (profiles/r01_block_sweep.txt)
   bool prof = false;
   std::map<std::string, Prof> profs;
@@ -159,6 +160,7 @@ struct fus_op
   void *d_G = nullptr, *d_detJ = nullptr, *d_Dg = nullptr, *d_partial = nullptr;
   void *d_tmp_x = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr, *d_tmp_coef = nullptr;
   size_t lds_bytes = 0;
+  int deterministic = 0;
   // neighbours (multi-GPU)
   std::vector<Neigh> neigh;
   int32_t* d_uidx = nullptr;  // unique interface dofs (internal)
@@ -241,8 +243,8 @@ struct ProfScope
 // -------------------------------------------------------------------------------------------------
 // typed implementation
 // -------------------------------------------------------------------------------------------------
-template <typename T, int P, int OP>
-static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec)
+template <typename T, int P, int OP, int ATOMIC>
+static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec)
 {
   constexpr int N = P + 1;
   DTab<T, N> Dk;
@@ -251,15 +253,22 @@ static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, 
   static bool attr_set = false;  // per instantiation
   if (!attr_set)
   {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_block_op<T, P, OP>), dim3(op->L.nblocks), dim3(64 * op->L.waves),
+  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC>), dim3(op->L.nblocks), dim3(64 * op->L.waves),
                      op->lds_bytes, op->ctx->stream, op->A, Dk, static_cast<const T*>(op->d_Dg),
                      geo, coef, x, bvec, static_cast<T*>(op->d_partial));
   HIPCHK(hipGetLastError());
   return FUS_OK;
+}
+
+template <typename T, int P, int OP>
+static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec)
+{
+  return op->deterministic ? launch_block_op_v<T, P, OP, 0>(op, geo, coef, x, bvec)
+                           : launch_block_op_v<T, P, OP, 1>(op, geo, coef, x, bvec);
 }
 
 // b_internal = A x_internal  (all dofs: interior written by the block kernel, shared reduced)
@@ -956,6 +965,8 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
       return fail(FUS_ERR_ARG, "waves must be 1, 2 or 4");
     c->waves = (int)value;
   }
+  else if (!strcmp(key, "deterministic"))
+    c->deterministic = value != 0;
   else
     return fail(FUS_ERR_ARG, std::string("unknown option ") + key);
   return FUS_OK;
@@ -976,7 +987,7 @@ int fus_comm_init(fus_ctx* c, int rank, int nranks, const void* id128)
   if (!c || nranks < 1 || rank < 0 || rank >= nranks)
     return fail(FUS_ERR_ARG, "bad rank/nranks");
   c->rank = rank, c->nranks = nranks;
-  if (nranks == 1)
+  if (nranks == 1 && !id128)
     return FUS_OK;
   FUSCHK(rccl_load());
   ncclUniqueId id;
@@ -1048,6 +1059,7 @@ int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_
     return fail(FUS_ERR_ARG, "nodes1d are not the GLL points of [0,1]");
   HIPCHK(hipSetDevice(c->device));
   std::unique_ptr<fus_op> op(new fus_op());
+  op->deterministic = c->deterministic;
   op->ctx = c, op->P = P, op->N = N, op->Nd = N * N * N, op->dtype = dtype;
   op->ts = dtype == FUS_F64 ? 8 : 4;
   op->ncells = ncells, op->ndofs = ndofs, op->nnodes = nnodes;

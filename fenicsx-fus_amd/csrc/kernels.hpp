@@ -128,7 +128,9 @@ __device__ __forceinline__ void elem_fetch(ElemIn<T, N, OP>& in, int er, const T
 }
 
 // One element's operator action, accumulated into the block's LDS vector y_l.
-template <typename T, int N, int OP>
+// ATOMIC: the accumulation is an LDS floating-point atomic (ds_add_f64 / ds_add_f32), so waves need
+// not proceed in conflict-free rounds; otherwise a plain read-modify-write (deterministic).
+template <typename T, int N, int OP, int ATOMIC>
 __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP>& in, const DTab<T, N>& Dk,
                                              const T (&Drb)[N], const T (&Drc)[N], const T (&Dcb)[N],
                                              const T (&Dcc)[N], const T* __restrict__ x_l,
@@ -250,14 +252,19 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP>& in, const D
   // share no dof and rounds are ordered -> deterministic
 #pragma unroll
   for (int a = 0; a < N; ++a)
-    y_l[li[a]] += Y[a];
+  {
+    if (ATOMIC)
+      __hip_atomic_fetch_add(&y_l[li[a]], Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+      y_l[li[a]] += Y[a];
+  }
 }
 
 // Block operator:  bvec[interior dofs of block] = (A x)[...],  partial[(block, shared slot)] =
 // this block's contribution to a shared dof.  x, bvec in internal numbering.
 // geo = G (6*Nd per element, per-lane vector layout) for OP_STIFFNESS, detJw (Nd per element,
 // tensor order) for OP_MASS.  coef: one scalar per internal element.
-template <typename T, int P, int OP>
+template <typename T, int P, int OP, int ATOMIC>
 __global__ void __launch_bounds__(256)
 k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
            const T* __restrict__ geo, const T* __restrict__ coef, const T* __restrict__ x,
@@ -287,11 +294,27 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   const int b = p / N, c = p - b * N;
   const bool active = s < EPW;
   const int slots = A.waves * EPW;
-  const int16_t* rtab = A.rounds + sh.rounds_off + wave * EPW + (active ? s : 0);
+  const int myslot = wave * EPW + (active ? s : 0);
+  // element of this lane group in trip r: conflict-free round table (deterministic mode) or simply
+  // the next `slots` elements (atomic mode: no ordering constraint between waves)
+  const int ntrips = ATOMIC ? (sh.nelem + slots - 1) / slots : sh.nrounds;
+  auto elem_of = [&](int r) -> int
+  {
+    if (!active || r >= ntrips)
+      return -1;
+    if (ATOMIC)
+      return (r * slots + myslot < sh.nelem) ? r * slots + myslot : -1;
+    return (int)rt_l[r * slots + myslot];
+  };
 
-  // first round's geometry is requested before the block's dof values are staged
+  // first trip's geometry is requested before the block's dof values are staged
   ElemIn<T, N, OP> inA, inB;
-  elem_fetch<T, N, OP>(inA, (active && sh.nrounds > 0) ? (int)rtab[0] : -1, geo, elem_off, p);
+  {
+    int e0 = -1;
+    if (active && ntrips > 0)
+      e0 = ATOMIC ? (myslot < sh.nelem ? myslot : -1) : (int)A.rounds[sh.rounds_off + myslot];
+    elem_fetch<T, N, OP>(inA, e0, geo, elem_off, p);
+  }
 
   // ---- prologue: stage the block's dof values in LDS, clear the accumulator; all loads of a
   // pass are issued before the first LDS store so one HBM round trip covers the whole block ----
@@ -373,21 +396,19 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     Dcc[j] = (OP == OP_STIFFNESS) ? D_l[j * N + c] : T(0);
   }
 
-  // ---- rounds, two per trip: while one register set is consumed the other is in flight ----
-  for (int r = 0; r < sh.nrounds; r += 2)
+  // ---- trips, two per iteration: while one register set is consumed the other is in flight ----
+  for (int r = 0; r < ntrips; r += 2)
   {
-    const bool has1 = r + 1 < sh.nrounds, has2 = r + 2 < sh.nrounds;
-    elem_fetch<T, N, OP>(inB, (active && has1) ? (int)rt_l[(r + 1) * slots + wave * EPW + s] : -1, geo,
-                         elem_off, p);
-    elem_compute<T, N, OP>(inA, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, p, b, c);
-    if (A.waves > 1)
+    const bool has1 = r + 1 < ntrips;
+    elem_fetch<T, N, OP>(inB, elem_of(r + 1), geo, elem_off, p);
+    elem_compute<T, N, OP, ATOMIC>(inA, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, p, b, c);
+    if (!ATOMIC && A.waves > 1)
       __syncthreads();
-    elem_fetch<T, N, OP>(inA, (active && has2) ? (int)rt_l[(r + 2) * slots + wave * EPW + s] : -1, geo,
-                         elem_off, p);
+    elem_fetch<T, N, OP>(inA, elem_of(r + 2), geo, elem_off, p);
     if (has1)
     {
-      elem_compute<T, N, OP>(inB, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, p, b, c);
-      if (A.waves > 1)
+      elem_compute<T, N, OP, ATOMIC>(inB, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, p, b, c);
+      if (!ATOMIC && A.waves > 1)
         __syncthreads();
     }
   }

@@ -69,13 +69,16 @@ def dtype_code(dt) -> int:
 class Context:
     """One per GPU (fus_init)."""
 
-    def __init__(self, device: int = 0, block_elems: int | None = None, waves: int | None = None):
+    def __init__(self, device: int = 0, block_elems: int | None = None, waves: int | None = None,
+                 deterministic: bool | None = None):
         self.h = C.c_void_p()
         check(lib().fus_init(C.c_int(device), C.byref(self.h)))
         if block_elems is not None:
             self.set_option("block_elems", block_elems)
         if waves is not None:
             self.set_option("waves", waves)
+        if deterministic is not None:
+            self.set_option("deterministic", int(deterministic))
         self.rank, self.nranks = 0, 1
 
     def set_option(self, key: str, value: int):

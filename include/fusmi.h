@@ -49,7 +49,9 @@ int fus_init(int device, fus_ctx** ctx);
 int fus_finalize(fus_ctx* ctx);
 int fus_synchronize(fus_ctx* ctx);
 /* Tunables, set before fus_op_create: "block_elems" (elements per LDS block, default 32),
- * "waves" (waves per workgroup, default 4).  Unknown keys -> FUS_ERR_ARG. */
+ * "waves" (waves per workgroup, default 4), "deterministic" (1: elements accumulate in
+ * conflict-free rounds, results bitwise reproducible; 0 (default): LDS floating-point atomics, the
+ * order of the <= 8 adds per DOF inside a block is free).  Unknown keys -> FUS_ERR_ARG. */
 int fus_set_option(fus_ctx* ctx, const char* key, int64_t value);
 
 /* Multi-GPU: one process per GPU.  fus_comm_unique_id fills a 128-byte RCCL id on rank 0; the

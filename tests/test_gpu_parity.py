@@ -53,11 +53,12 @@ def test_stiffness_and_mass_vs_oracle(orc, ctx, P, perturb):
     d.close()
 
 
+@pytest.mark.parametrize("det", [0, 1])
 @pytest.mark.parametrize("be,w", [(16, 1), (16, 2), (7, 4), (64, 4), (200, 4)])
-def test_block_shapes_and_waves(orc, be, w):
-    # ragged blocks / single-wave workgroups / one block for the whole mesh
+def test_block_shapes_and_waves(orc, be, w, det):
+    # ragged blocks / single-wave workgroups / one block for the whole mesh, both accumulation modes
     pr = Problem(orc, (5, 4, 3), 4, perturb=0.1)
-    c = fa.Context(0, block_elems=be, waves=w)
+    c = fa.Context(0, block_elems=be, waves=w, deterministic=bool(det))
     d = fa.SpectralOperatorData(pr.V, c)
     x = np.random.default_rng(0).standard_normal(pr.ndofs)
     coef = np.full(pr.mesh.num_cells, -1.0 / 3)
@@ -97,15 +98,19 @@ def test_node_order_invariance_gpu(orc, ctx):
     da.close(), db.close()
 
 
-def test_bitwise_reproducible(orc, ctx):
+def test_bitwise_reproducible(orc):
+    # deterministic mode: conflict-free rounds, fixed summation order
     pr = Problem(orc, (8, 8, 8), 4, perturb=0.1)
+    ctx = fa.Context(0, deterministic=True)
     d = fa.SpectralOperatorData(pr.V, ctx)
     x = np.random.default_rng(2).standard_normal(pr.ndofs)
     coef = np.ones(pr.mesh.num_cells)
     y1 = d.stiffness(x, coef, np.zeros(pr.ndofs))
     y2 = d.stiffness(x, coef, np.zeros(pr.ndofs))
     assert np.array_equal(y1, y2)
+    assert relmax(y1, pr.K(x, coef)) < TOL_OP
     d.close()
+    ctx.close()
 
 
 def test_fp32_operator(orc, ctx):

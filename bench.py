@@ -86,7 +86,7 @@ def main():
     ap.add_argument("--deterministic", type=int, default=None, help="1: conflict-free rounds, 0: LDS atomics")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=32)
-    ap.add_argument("--cpu-steps", type=int, default=10)
+    ap.add_argument("--cpu-steps", type=int, default=60)
     args = ap.parse_args()
 
     import torch
@@ -160,6 +160,14 @@ def main():
         avg_ms = k_ms / max(k_cnt, 1)
         achieved = b_stiff * ndl / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         value = ndofs_global * args.steps / elapsed
+        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
+        # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01_pmc_traffic.json); only quoted
+        # for the configuration those passes were taken on
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if (os.path.exists(pmc) and n == 64 and P == 4 and args.block_elems is None and args.waves is None
+                and not args.deterministic):
+            traffic = json.load(open(pmc))["k_block_op_stiffness"]["hbm_bytes_per_launch"]
         out = {
             "metric": "DOF-updates/sec (RK4 step) at p=4 hex fp64",
             "value": value,
@@ -178,8 +186,9 @@ def main():
                        "cells_per_gpu": int(nc), "geometry": "general (G streamed, 6 fp64 per point)",
                        "partition": f"x-slabs x{world}", "blocks": info["nblocks"],
                        "lds_bytes_per_block": info["lds_bytes"], "dt": dt},
-            "roofline": {"bound": "hbm", "kernel": "k_block_op<double,4,stiffness>", "achieved": achieved,
-                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "k_block_op<double,4,stiffness>" if not args.deterministic else "k_block_op<double,4,stiffness,rounds>", "achieved": achieved,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)",
                          "algorithmic_bytes_per_launch": b_stiff * ndl, "avg_launch_ms": avg_ms,
                          "launches": k_cnt},
             "step_roofline": {"algorithmic_bytes_per_dof_update": b_general,

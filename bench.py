@@ -153,21 +153,26 @@ def main():
         N3 = (P + 1) ** 3
         ndl = V.num_dofs
         rho_e = nc * N3 / ndl
-        # per stage  stiffness = rho_e (s + 4 + 6 s) + s ; stage update = 12 s
+        # SURVEY 8d, per stage and DOF: stiffness = rho_e (s + 4 + 6 s) + s ; stage update = 12 s.
+        # One launch of the dominant kernel does the stiffness action for every DOF and the fused
+        # stage update for the block-interior DOFs it completes (the shared DOFs' update runs in
+        # k_stage on the shared range).
         b_stiff = rho_e * (s + 4 + 6 * s) + s
         b_general = 4 * (b_stiff + 12 * s)
+        n_int = info["interior_dofs"]
+        alg_launch = b_stiff * ndl + 12 * s * n_int
         k_ms, k_cnt = prof["stiffness"]
         avg_ms = k_ms / max(k_cnt, 1)
-        achieved = b_stiff * ndl / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+        achieved = alg_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         value = ndofs_global * args.steps / elapsed
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
         # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01_pmc_traffic.json); only quoted
         # for the configuration those passes were taken on
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
         if (os.path.exists(pmc) and n == 64 and P == 4 and args.block_elems is None and args.waves is None
                 and not args.deterministic):
-            traffic = json.load(open(pmc))["k_block_op_stiffness"]["hbm_bytes_per_launch"]
+            traffic = json.load(open(pmc))["k_block_op_fused"]["hbm_bytes_per_launch"]
         out = {
             "metric": "DOF-updates/sec (RK4 step) at p=4 hex fp64",
             "value": value,
@@ -186,10 +191,10 @@ def main():
                        "cells_per_gpu": int(nc), "geometry": "general (G streamed, 6 fp64 per point)",
                        "partition": f"x-slabs x{world}", "blocks": info["nblocks"],
                        "lds_bytes_per_block": info["lds_bytes"], "dt": dt},
-            "roofline": {"bound": "hbm", "kernel": "k_block_op<double,4,stiffness>" if not args.deterministic else "k_block_op<double,4,stiffness,rounds>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": "k_block_op<double,4,stiffness,+fused RK4 stage>", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "traffic_source": "profiles/r01_pmc_traffic.json (separate rocprofv3 --pmc passes)",
-                         "algorithmic_bytes_per_launch": b_stiff * ndl, "avg_launch_ms": avg_ms,
+                         "traffic_source": "profiles/r01c_pmc_traffic.json (separate rocprofv3 --pmc passes)",
+                         "algorithmic_bytes_per_launch": alg_launch, "interior_dofs": n_int, "avg_launch_ms": avg_ms,
                          "launches": k_cnt},
             "step_roofline": {"algorithmic_bytes_per_dof_update": b_general,
                               "achieved_GBps": b_general * value / world / 1e9,

@@ -176,8 +176,12 @@ struct fus_model
   double freq, amp, speed;
   void *u0 = nullptr, *v0 = nullptr, *u_ = nullptr, *v_ = nullptr, *un = nullptr, *vn = nullptr,
        *b = nullptr, *minv = nullptr, *m = nullptr, *coef = nullptr;
-  int64_t nb = 0;  // boundary dofs
+  // boundary dofs (diagonal source / absorbing weights), sorted by internal index:
+  // [0, nb_int) are block-interior (applied in the fused epilogue through d_blk_bnd_off),
+  // [nb_int, nb) are shared dofs (applied by k_boundary after the partial sums are reduced)
+  int64_t nb = 0, nb_int = 0;
   int32_t* d_bidx = nullptr;
+  int32_t* d_blk_bnd_off = nullptr;
   void *d_bsrc = nullptr, *d_babs = nullptr;
   std::vector<void*> allocs;
   bool initialised = false;
@@ -243,8 +247,9 @@ struct ProfScope
 // -------------------------------------------------------------------------------------------------
 // typed implementation
 // -------------------------------------------------------------------------------------------------
-template <typename T, int P, int OP, int ATOMIC>
-static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec)
+template <typename T, int P, int OP, int ATOMIC, int STAGE>
+static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec,
+                             const StageArgs<T>& S)
 {
   constexpr int N = P + 1;
   DTab<T, N> Dk;
@@ -253,22 +258,38 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
   static bool attr_set = false;  // per instantiation
   if (!attr_set)
   {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC>), dim3(op->L.nblocks), dim3(64 * op->L.waves),
-                     op->lds_bytes, op->ctx->stream, op->A, Dk, static_cast<const T*>(op->d_Dg),
-                     geo, coef, x, bvec, static_cast<T*>(op->d_partial));
+  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC, STAGE>), dim3(op->L.nblocks),
+                     dim3(64 * op->L.waves), op->lds_bytes, op->ctx->stream, op->A, Dk,
+                     static_cast<const T*>(op->d_Dg), geo, coef, x, bvec,
+                     static_cast<T*>(op->d_partial), S);
   HIPCHK(hipGetLastError());
   return FUS_OK;
 }
 
-template <typename T, int P, int OP>
-static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec)
+template <typename T, int P, int OP, int STAGE>
+static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec,
+                           const StageArgs<T>& S)
 {
-  return op->deterministic ? launch_block_op_v<T, P, OP, 0>(op, geo, coef, x, bvec)
-                           : launch_block_op_v<T, P, OP, 1>(op, geo, coef, x, bvec);
+  return op->deterministic ? launch_block_op_v<T, P, OP, 0, STAGE>(op, geo, coef, x, bvec, S)
+                           : launch_block_op_v<T, P, OP, 1, STAGE>(op, geo, coef, x, bvec, S);
+}
+
+template <typename T>
+static int shared_reduce(fus_op* op, T* bvec)
+{
+  if (op->L.n_shared > 0)
+  {
+    ProfScope ps(op->ctx, "shared");
+    hipLaunchKernelGGL((k_shared_reduce<T>), dim3(nblk(op->L.n_shared)), dim3(256), 0,
+                       op->ctx->stream, op->L.n_shared, op->d_sh_ptr, op->d_sh_pairs,
+                       static_cast<const T*>(op->d_partial), bvec + op->L.n_int_pad);
+    HIPCHK(hipGetLastError());
+  }
+  return FUS_OK;
 }
 
 // b_internal = A x_internal  (all dofs: interior written by the block kernel, shared reduced)
@@ -279,17 +300,10 @@ static int apply_internal(fus_op* op, const T* coef, const T* x, T* bvec)
   {
     ProfScope ps(c, OP == OP_STIFFNESS ? "stiffness" : "mass");
     const T* geo = static_cast<const T*>(OP == OP_STIFFNESS ? op->d_G : op->d_detJ);
-    FUSCHK((launch_block_op<T, P, OP>(op, geo, coef, x, bvec)));
+    StageArgs<T> none{};
+    FUSCHK((launch_block_op<T, P, OP, STAGE_NONE>(op, geo, coef, x, bvec, none)));
   }
-  if (op->L.n_shared > 0)
-  {
-    ProfScope ps(c, "shared");
-    hipLaunchKernelGGL((k_shared_reduce<T>), dim3(nblk(op->L.n_shared)), dim3(256), 0, c->stream,
-                       op->L.n_shared, op->d_sh_ptr, op->d_sh_pairs,
-                       static_cast<const T*>(op->d_partial), bvec + op->L.n_int_pad);
-    HIPCHK(hipGetLastError());
-  }
-  return FUS_OK;
+  return shared_reduce<T>(op, bvec);
 }
 
 // Shared-DOF exchange of a partial-sum vector (replaces b->scatter_rev(std::plus) +
@@ -677,6 +691,16 @@ static int model_setup_finish(fus_model* m)
       babs.push_back(absb[i]);
     }
   m->nb = (int64_t)bidx.size();
+  {
+    const Layout& L = op->L;
+    m->nb_int = std::lower_bound(bidx.begin(), bidx.end(), (int32_t)L.n_int_pad) - bidx.begin();
+    std::vector<int32_t> off(L.nblocks + 1);
+    for (int32_t b = 0; b < L.nblocks; ++b)
+      off[b] = (int32_t)(std::lower_bound(bidx.begin(), bidx.begin() + m->nb_int, L.blk_int_off[b])
+                         - bidx.begin());
+    off[L.nblocks] = (int32_t)m->nb_int;
+    FUSCHK(upload(m->allocs, &m->d_blk_bnd_off, off, st));
+  }
   T *d_bsrc, *d_babs;
   FUSCHK(upload(m->allocs, &m->d_bidx, bidx, st));
   FUSCHK(upload(m->allocs, &d_bsrc, bsrc, st));
@@ -718,38 +742,70 @@ static StageScalars stage_scalars(const fus_model* m, int i, double t_, double d
   return sc;
 }
 
-// Stage i, first half: b = K(-1/rho) u_stage (this rank's cells), interface partials packed.
+template <typename T>
+static StageArgs<T> stage_args(fus_model* m, const StageScalars& sc)
+{
+  StageArgs<T> S;
+  S.minv = static_cast<const T*>(m->minv);
+  S.vn = static_cast<T*>(m->vn), S.un = static_cast<T*>(m->un);
+  S.u0 = static_cast<T*>(m->u0), S.v0 = static_cast<T*>(m->v0);
+  S.u_ = static_cast<T*>(m->u_), S.v_ = static_cast<T*>(m->v_);
+  S.adt = (T)sc.adt, S.bdt = (T)sc.bdt, S.gval = (T)sc.gval;
+  S.blk_bnd_off = m->d_blk_bnd_off, S.bnd_idx = m->d_bidx;
+  S.bnd_src = static_cast<const T*>(m->d_bsrc), S.bnd_abs = static_cast<const T*>(m->d_babs);
+  return S;
+}
+
+// Stage i, first half: the block kernel applies K(-1/rho) to u_stage and, for every block-interior
+// dof, finishes the stage right away (boundary terms, kv = b/m, axpys); shared dofs leave as partial
+// sums, are reduced into b's shared range, and the interface entries are packed for the exchange.
 template <typename T, int P>
-static int stage_begin(fus_model* m, int i)
+static int stage_begin(fus_model* m, int i, double t, double dt)
 {
   fus_op* op = m->op;
   const T* ustage = static_cast<const T*>(i == 0 ? m->u0 : m->un);  // a_0 = 0: un == u0
   T* b = static_cast<T*>(m->b);
-  FUSCHK((apply_internal<T, P, OP_STIFFNESS>(op, static_cast<const T*>(m->coef), ustage, b)));
+  const StageArgs<T> S = stage_args<T>(m, stage_scalars<T>(m, i, t, dt));
+  const T* G = static_cast<const T*>(op->d_G);
+  const T* coef = static_cast<const T*>(m->coef);
+  {
+    ProfScope ps(m->ctx, "stiffness");
+    if (i == 0)
+      FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 0>(op, G, coef, ustage, b, S)));
+    else if (i == 3)
+      FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 3>(op, G, coef, ustage, b, S)));
+    else
+      FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 1>(op, G, coef, ustage, b, S)));
+  }
+  FUSCHK(shared_reduce<T>(op, b));
   return halo_pack<T>(op, b);
 }
 
-// Stage i, second half: ordered sum of the sharers' partials, boundary terms, fused update.
+// Stage i, second half, shared dofs only: ordered sum of the sharers' partials, boundary terms,
+// the same fused update on the shared range of the internal vectors.
 template <typename T>
 static int stage_end(fus_model* m, int i, double t, double dt)
 {
   fus_op* op = m->op;
   fus_ctx* c = m->ctx;
   hipStream_t st = c->stream;
-  const int64_t n = op->L.n_internal;
+  const int64_t off = op->L.n_int_pad, n = op->L.n_internal - off;  // both multiples of 16
   const StageScalars sc = stage_scalars<T>(m, i, t, dt);
   T *u0 = static_cast<T*>(m->u0), *v0 = static_cast<T*>(m->v0), *u_ = static_cast<T*>(m->u_),
     *v_ = static_cast<T*>(m->v_), *un = static_cast<T*>(m->un), *vn = static_cast<T*>(m->vn),
     *b = static_cast<T*>(m->b);
   const T* minv = static_cast<const T*>(m->minv);
   FUSCHK(halo_unpack<T>(op, b));
-  if (m->nb > 0)
+  const int64_t nbs = m->nb - m->nb_int;
+  if (nbs > 0)
   {
     ProfScope ps(c, "boundary");
-    hipLaunchKernelGGL((k_boundary<T>), dim3(nblk(m->nb)), dim3(256), 0, st, m->nb, m->d_bidx,
-                       static_cast<const T*>(m->d_bsrc), static_cast<const T*>(m->d_babs),
-                       (T)sc.gval, (i == 0) ? v0 : vn, b);
+    hipLaunchKernelGGL((k_boundary<T>), dim3(nblk(nbs)), dim3(256), 0, st, nbs,
+                       m->d_bidx + m->nb_int, static_cast<const T*>(m->d_bsrc) + m->nb_int,
+                       static_cast<const T*>(m->d_babs) + m->nb_int, (T)sc.gval,
+                       (i == 0) ? v0 : vn, b);
   }
+  if (n > 0)
   {
     ProfScope ps(c, "stage");
     const unsigned grid = (unsigned)std::min<int64_t>(nblk(n / (16 / sizeof(T))), 256 * 16);
@@ -757,16 +813,16 @@ static int stage_end(fus_model* m, int i, double t, double dt)
     switch (i)
     {
     case 0:
-      hipLaunchKernelGGL((k_stage<T, 0>), dim3(grid), dim3(256), 0, st, n, b, minv, vn, un, u0, v0,
-                         u_, v_, adt, bdt);
+      hipLaunchKernelGGL((k_stage<T, 0>), dim3(grid), dim3(256), 0, st, n, b + off, minv + off,
+                         vn + off, un + off, u0 + off, v0 + off, u_ + off, v_ + off, adt, bdt);
       break;
     case 3:
-      hipLaunchKernelGGL((k_stage<T, 3>), dim3(grid), dim3(256), 0, st, n, b, minv, vn, un, u0, v0,
-                         u_, v_, adt, bdt);
+      hipLaunchKernelGGL((k_stage<T, 3>), dim3(grid), dim3(256), 0, st, n, b + off, minv + off,
+                         vn + off, un + off, u0 + off, v0 + off, u_ + off, v_ + off, adt, bdt);
       break;
     default:
-      hipLaunchKernelGGL((k_stage<T, 1>), dim3(grid), dim3(256), 0, st, n, b, minv, vn, un, u0, v0,
-                         u_, v_, adt, bdt);
+      hipLaunchKernelGGL((k_stage<T, 1>), dim3(grid), dim3(256), 0, st, n, b + off, minv + off,
+                         vn + off, un + off, u0 + off, v0 + off, u_ + off, v_ + off, adt, bdt);
     }
   }
   HIPCHK(hipGetLastError());
@@ -780,7 +836,7 @@ static int model_step(fus_model* m, double t, double dt)
 {
   for (int i = 0; i < 4; ++i)
   {
-    FUSCHK((stage_begin<T, P>(m, i)));
+    FUSCHK((stage_begin<T, P>(m, i, t, dt)));
     if (!m->op->neigh.empty())
     {
       ProfScope ps(m->ctx, "halo");
@@ -872,9 +928,9 @@ static int d_model_step(fus_model* m, double t, double dt)
 {
   FUS_DISPATCH(m->op->dtype, m->op->P, (model_step<TT, PP>(m, t, dt)));
 }
-static int d_stage_begin(fus_model* m, int i)
+static int d_stage_begin(fus_model* m, int i, double t, double dt)
 {
-  FUS_DISPATCH(m->op->dtype, m->op->P, (stage_begin<TT, PP>(m, i)));
+  FUS_DISPATCH(m->op->dtype, m->op->P, (stage_begin<TT, PP>(m, i, t, dt)));
 }
 static int d_stage_end(fus_model* m, int i, double t, double dt)
 {
@@ -898,6 +954,48 @@ static int d_halo_unpack(fus_op* op, void* v)
 {
   return op->dtype == FUS_F64 ? halo_unpack<double>(op, static_cast<double*>(v))
                               : halo_unpack<float>(op, static_cast<float*>(v));
+}
+
+// (Re)build the block layout and the device-side operator data.  force_shared marks dofs held by
+// other ranks too: they must never be finished inside a block's fused epilogue.
+static int op_build(fus_op* op, const uint8_t* force_shared)
+{
+  fus_ctx* c = op->ctx;
+  for (void* q : op->allocs)
+    (void)hipFree(q);
+  op->allocs.clear();
+  // centroids for the block partitioner
+  std::vector<double> cen((size_t)op->ncells * 3, 0.0);
+  for (int64_t cidx = 0; cidx < op->ncells; ++cidx)
+    for (int v = 0; v < 8; ++v)
+      for (int j = 0; j < 3; ++j)
+      {
+        const size_t k = 3 * (size_t)op->h_geom_dm[cidx * 8 + v] + j;
+        cen[3 * cidx + j] +=
+            0.125 * (op->dtype == FUS_F64 ? reinterpret_cast<const double*>(op->h_geom_x.data())[k]
+                                          : (double)reinterpret_cast<const float*>(op->h_geom_x.data())[k]);
+      }
+  // blocks must fit the CU's 160 KB of LDS: halve the block size until they do
+  for (int be = c->block_elems;; be = (be + 1) / 2)
+  {
+    std::string err = build_layout(op->L, op->P, op->ncells, op->ndofs, op->h_dofmap.data(),
+                                   cen.data(), be, c->waves, force_shared);
+    const bool too_big = err.empty() ? op->L.lds_bytes(op->ts) + 64 > 160 * 1024
+                                     : err.find("65535") != std::string::npos;
+    if (too_big && be > 1)
+      continue;
+    if (!err.empty())
+      return fail(FUS_ERR_ARG, "layout: " + err);
+    break;
+  }
+  int r = d_op_setup(op);
+  if (r != FUS_OK)
+  {
+    for (void* q : op->allocs)
+      (void)hipFree(q);
+    op->allocs.clear();
+  }
+  return r;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -1073,35 +1171,9 @@ int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_
   for (int64_t k = 0; k < ncells * 8; ++k)
     if (geom_dofmap[k] < 0 || geom_dofmap[k] >= nnodes)
       return fail(FUS_ERR_ARG, "geometry dofmap entry out of range");
-  // centroids for the block partitioner
-  std::vector<double> cen((size_t)ncells * 3, 0.0);
-  for (int64_t cidx = 0; cidx < ncells; ++cidx)
-    for (int v = 0; v < 8; ++v)
-      for (int j = 0; j < 3; ++j)
-      {
-        const size_t k = 3 * (size_t)geom_dofmap[cidx * 8 + v] + j;
-        cen[3 * cidx + j] += 0.125 * (dtype == FUS_F64 ? static_cast<const double*>(geom_x)[k]
-                                                       : (double)static_cast<const float*>(geom_x)[k]);
-      }
-  // blocks must fit the CU's 160 KB of LDS: halve the block size until they do
-  for (int be = c->block_elems;; be = (be + 1) / 2)
-  {
-    std::string err = build_layout(op->L, P, ncells, ndofs, tensor_dofmap, cen.data(), be, c->waves);
-    const bool too_big = err.empty() ? op->L.lds_bytes(op->ts) + 64 > 160 * 1024
-                                     : err.find("65535") != std::string::npos;
-    if (too_big && be > 1)
-      continue;
-    if (!err.empty())
-      return fail(FUS_ERR_ARG, "layout: " + err);
-    break;
-  }
-  int r = d_op_setup(op.get());
+  int r = op_build(op.get(), nullptr);
   if (r != FUS_OK)
-  {
-    for (void* q : op->allocs)
-      (void)hipFree(q);
     return r;
-  }
   *out = op.release();
   return FUS_OK;
 }
@@ -1212,6 +1284,23 @@ int fus_op_set_neighbours(fus_op* op, int nneigh, const int32_t* ranks, const in
     return fail(FUS_ERR_ARG, "null argument");
   HIPCHK(hipSetDevice(op->ctx->device));
   hipStream_t st = op->ctx->stream;
+  if (!op->neigh.empty())
+    return fail(FUS_ERR_STATE, "neighbours already set");
+  {
+    // dofs other ranks hold as well are classified shared: rebuild the layout with that mask
+    int64_t total = 0;
+    for (int k = 0; k < nneigh; ++k)
+      total += counts[k];
+    std::vector<uint8_t> mask(op->ndofs, 0);
+    for (int64_t j = 0; j < total; ++j)
+    {
+      if (dof_idx[j] < 0 || dof_idx[j] >= op->ndofs)
+        return fail(FUS_ERR_ARG, "shared dof index out of range");
+      mask[dof_idx[j]] = 1;
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    FUSCHK(op_build(op, mask.data()));
+  }
   std::vector<std::pair<int, int>> order;  // (rank, k)
   std::vector<int64_t> off(nneigh + 1, 0);
   for (int k = 0; k < nneigh; ++k)
@@ -1341,7 +1430,7 @@ int fus_group_rk4_steps(fus_model** ms, int n, double t0, double dt, int64_t nst
     for (int st = 0; st < 4; ++st)
     {
       for (int i = 0; i < n; ++i)
-        FUSCHK(d_stage_begin(ms[i], st));   // includes the pack
+        FUSCHK(d_stage_begin(ms[i], st, t, dt));   // includes the pack
       std::vector<fus_op*> ops(n);
       for (int i = 0; i < n; ++i)
         ops[i] = ms[i]->op;

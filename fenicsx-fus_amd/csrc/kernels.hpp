@@ -46,6 +46,26 @@ struct BlockArgs
   int32_t waves;
 };
 
+// Arguments of the fused RK4 stage epilogue of k_block_op (STAGE >= 0): the model vectors in
+// internal numbering, the stage's scalars and the boundary entries of block-interior dofs
+// (sorted by internal index, blk_bnd_off[b]..blk_bnd_off[b+1] belong to block b).
+template <typename T>
+struct StageArgs
+{
+  const T* minv;
+  T *vn, *un, *u0, *v0, *u_, *v_;
+  T adt, bdt, gval;
+  const int32_t* blk_bnd_off;
+  const int32_t* bnd_idx;
+  const T* bnd_src;
+  const T* bnd_abs;
+};
+
+enum
+{
+  STAGE_NONE = -1  // plain operator action: b / partial slab are written, no update
+};
+
 template <typename T, int N>
 struct DTab
 {
@@ -264,11 +284,16 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP>& in, const D
 // this block's contribution to a shared dof.  x, bvec in internal numbering.
 // geo = G (6*Nd per element, per-lane vector layout) for OP_STIFFNESS, detJw (Nd per element,
 // tensor order) for OP_MASS.  coef: one scalar per internal element.
-template <typename T, int P, int OP, int ATOMIC>
+//
+// STAGE >= 0 (stiffness only) fuses the RK4 stage update into the epilogue (Linear.hpp:274-294 +
+// :203-221): for the block's interior dofs the sum in LDS is complete, so b never goes to HBM --
+// boundary terms are added in LDS, kv = b * minv, and u_, v_, un', vn' (or the new u0, v0 at stage 3)
+// are written straight from here.  Shared dofs still leave as partial sums.
+template <typename T, int P, int OP, int ATOMIC, int STAGE>
 __global__ void __launch_bounds__(256)
 k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
            const T* __restrict__ geo, const T* __restrict__ coef, const T* __restrict__ x,
-           T* __restrict__ bvec, T* __restrict__ partial)
+           T* __restrict__ bvec, T* __restrict__ partial, const StageArgs<T> S)
 {
   constexpr int N = P + 1, N2 = N * N, Nd = N * N * N;
   constexpr int EPW = (64 / N2) > 0 ? (64 / N2) : 1;
@@ -415,17 +440,85 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   __syncthreads();
 
   // ---- epilogue: each dof written once ----
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  const int nvec = sh.nint >> 1;
+  if (STAGE == STAGE_NONE)
   {
-    typedef T V2 __attribute__((ext_vector_type(2)));
     V2* bg = reinterpret_cast<V2*>(bvec + int_off);
-    const int nvec = sh.nint >> 1;
     for (int i = tid; i < nvec; i += nthr)
       bg[i] = reinterpret_cast<const V2*>(y_l)[i];
     if (tid == 0 && (sh.nint & 1))
       bvec[int_off + sh.nint - 1] = y_l[sh.nint - 1];
-    for (int l = sh.nint + tid; l < sh.nloc; l += nthr)
-      partial[sh_off + (l - sh.nint)] = y_l[l];
   }
+  else
+  {
+    // boundary terms of block-interior dofs (Linear.hpp:205; forms.py:38-39 collocated):
+    // b += g(t) src - abs * v_stage ; every entry is a distinct dof
+    const int k0 = S.blk_bnd_off[blk], k1 = S.blk_bnd_off[blk + 1];
+    if (k1 > k0)
+    {
+      const T* vstage = (STAGE == 0) ? S.v0 : S.vn;
+      for (int k = k0 + tid; k < k1; k += nthr)
+      {
+        const int gi = S.bnd_idx[k];
+        y_l[gi - int_off] += S.gval * S.bnd_src[k] - S.bnd_abs[k] * vstage[gi];
+      }
+      __syncthreads();
+    }
+    // fused stage update on the contiguous interior range (16-byte accesses); the scalar tail
+    // element of an odd range is handled by thread 0 with the same formulas
+    const int ntot = nvec + (sh.nint & 1);
+    for (int i = tid; i < ntot; i += nthr)
+    {
+      const bool tail = i >= nvec;
+      const int o = int_off + 2 * i;
+      V2 bv, mi, w, a0, b0, au, av;
+      auto ld = [&](const T* ptr) -> V2 {
+        V2 r;
+        if (!tail)
+          r = *reinterpret_cast<const V2*>(ptr + o);
+        else
+          r[0] = ptr[o], r[1] = T(0);
+        return r;
+      };
+      auto st = [&](T* ptr, V2 val) {
+        if (!tail)
+          *reinterpret_cast<V2*>(ptr + o) = val;
+        else
+          ptr[o] = val[0];
+      };
+      if (!tail)
+        bv = reinterpret_cast<const V2*>(y_l)[i];
+      else
+        bv[0] = y_l[2 * i], bv[1] = T(0);
+      mi = ld(S.minv);
+      const V2 kv = bv * mi;
+      if (STAGE == 0)
+      {
+        a0 = ld(S.u0), b0 = ld(S.v0);
+        st(S.u_, b0 * S.bdt + a0);
+        st(S.v_, kv * S.bdt + b0);
+        st(S.un, b0 * S.adt + a0);
+        st(S.vn, kv * S.adt + b0);
+      }
+      else if (STAGE == 3)
+      {
+        w = ld(S.vn), au = ld(S.u_), av = ld(S.v_);
+        st(S.u0, w * S.bdt + au);
+        st(S.v0, kv * S.bdt + av);
+      }
+      else
+      {
+        w = ld(S.vn), au = ld(S.u_), av = ld(S.v_), a0 = ld(S.u0), b0 = ld(S.v0);
+        st(S.u_, w * S.bdt + au);
+        st(S.v_, kv * S.bdt + av);
+        st(S.un, w * S.adt + a0);
+        st(S.vn, kv * S.adt + b0);
+      }
+    }
+  }
+  for (int l = sh.nint + tid; l < sh.nloc; l += nthr)
+    partial[sh_off + (l - sh.nint)] = y_l[l];
 }
 
 // bsh[s] = sum over the (block, slot) pairs of shared dof s, ascending block order

@@ -54,7 +54,8 @@ struct Rcb
 } // namespace
 
 std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
-                         const int32_t* dm, const double* centroids, int block_elems, int waves)
+                         const int32_t* dm, const double* centroids, int block_elems, int waves,
+                         const uint8_t* force_shared)
 {
   if (P < 1 || P > 15)
     return "unsupported degree";
@@ -99,6 +100,12 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
         }
       }
     }
+
+  // dofs other ranks also hold are never complete inside one block of this rank
+  if (force_shared)
+    for (int64_t g = 0; g < ndofs; ++g)
+      if (force_shared[g] && nblk[g] == 1)
+        nblk[g] = 2;
 
   // ---- 3. per block: rounds, local numbering, internal numbering ----
   L.cell_perm.resize(ncells);

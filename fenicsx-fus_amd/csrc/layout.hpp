@@ -65,10 +65,12 @@ struct Layout
 };
 
 // Builds the layout.  centroids: [ncells*3] (any consistent coordinates; used by the recursive
-// coordinate bisection that forms compact blocks).  Returns empty string or an error message.
+// coordinate bisection that forms compact blocks).  force_shared (optional, [ndofs]): dofs that must
+// be classified shared even if a single local block touches them (dofs held by other ranks too).
+// Returns empty string or an error message.
 std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
                          const int32_t* tensor_dofmap, const double* centroids, int block_elems,
-                         int waves);
+                         int waves, const uint8_t* force_shared = nullptr);
 
 // Internal consistency check used by fus_layout_check and the CPU tests.
 std::string verify_layout(const Layout& L, const int32_t* tensor_dofmap);

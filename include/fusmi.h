@@ -121,7 +121,9 @@ int fus_facet_diag(fus_op* op, int64_t nfacets, const int32_t* facet_cells,
 /* Shared-DOF description for >1 rank (replaces the IndexMap ghost/owner data behind
  * la::Vector::scatter_fwd/scatter_rev, Linear.hpp:196-206): for neighbour k, the local DOF
  * indices shared with rank ranks[k], counts[k] of them, concatenated in dof_idx; both sides
- * must list a shared set in the same (global id) order. */
+ * must list a shared set in the same (global id) order.  Call once, right after fus_op_create and
+ * before any model is created on the op (the block layout is rebuilt so that these DOFs are never
+ * finished inside a block's fused epilogue). */
 int fus_op_set_neighbours(fus_op* op, int nneigh, const int32_t* ranks, const int64_t* counts,
                           const int32_t* dof_idx);
 

@@ -182,6 +182,7 @@ struct fus_model
   int64_t nb = 0, nb_int = 0;
   int32_t* d_bidx = nullptr;
   int32_t* d_blk_bnd_off = nullptr;
+  int32_t *d_sh_ptr32 = nullptr, *d_sh_pairs32 = nullptr;  // shared CSR incl. boundary pseudo pairs
   void *d_bsrc = nullptr, *d_babs = nullptr;
   std::vector<void*> allocs;
   bool initialised = false;
@@ -284,8 +285,8 @@ static int shared_reduce(fus_op* op, T* bvec)
   if (op->L.n_shared > 0)
   {
     ProfScope ps(op->ctx, "shared");
-    hipLaunchKernelGGL((k_shared_reduce<T>), dim3(nblk(op->L.n_shared)), dim3(256), 0,
-                       op->ctx->stream, op->L.n_shared, op->d_sh_ptr, op->d_sh_pairs,
+    hipLaunchKernelGGL((k_shared_reduce<T, int64_t>), dim3(nblk(op->L.n_shared)), dim3(256), 0,
+                       op->ctx->stream, (int64_t)0, op->L.n_shared, op->d_sh_ptr, op->d_sh_pairs,
                        static_cast<const T*>(op->d_partial), bvec + op->L.n_int_pad);
     HIPCHK(hipGetLastError());
   }
@@ -481,7 +482,8 @@ static int op_setup_device(fus_op* op)
                      static_cast<T*>(op->d_detJ));
   HIPCHK(hipGetLastError());
 
-  FUSCHK(dalloc_bytes(pool, &op->d_partial, (size_t)L.npairs * sizeof(T), true, st));
+  // + one slot per shared dof for the boundary pseudo pairs of the models
+  FUSCHK(dalloc_bytes(pool, &op->d_partial, (size_t)(L.npairs + L.n_shared) * sizeof(T), true, st));
   FUSCHK(dalloc_bytes(pool, &op->d_tmp_x, (size_t)L.n_internal * sizeof(T), true, st));
   FUSCHK(dalloc_bytes(pool, &op->d_tmp_b, (size_t)L.n_internal * sizeof(T), true, st));
   FUSCHK(dalloc_bytes(pool, &op->d_tmp_c, (size_t)op->ndofs * sizeof(T), true, st));
@@ -665,8 +667,8 @@ static int model_setup(fus_model* m, const void* c0_, const void* rho0_, int64_t
   return FUS_OK;
 }
 
-// Setup vectors that need the sharers' contributions (m.scatter_rev(+), Linear.hpp:134, and the
-// facet integrals of cells owned by other ranks): m, src weights (in u_), abs weights (in v_)
+// Setup vectors: m (needs the sharers' contributions, m.scatter_rev(+), Linear.hpp:134), src
+// weights (parked in u_) and abs weights (parked in v_) of this rank's own facets
 static void* setup_halo_vector(fus_model* m, int k) { return k == 0 ? m->m : (k == 1 ? m->u_ : m->v_); }
 
 template <typename T>
@@ -700,6 +702,26 @@ static int model_setup_finish(fus_model* m)
                          - bidx.begin());
     off[L.nblocks] = (int32_t)m->nb_int;
     FUSCHK(upload(m->allocs, &m->d_blk_bnd_off, off, st));
+    // shared CSR of this model: the op's pairs + one trailing pseudo pair (slot npairs + k) for the
+    // k-th shared boundary dof, so the boundary term is the last addend like Linear.hpp:204-205
+    if (L.npairs + L.n_shared > 2000000000ll)
+      return fail(FUS_ERR_LIMIT, "partial slab exceeds int32 indexing");
+    std::vector<int32_t> extra(L.n_shared, -1);
+    for (int64_t k = m->nb_int; k < m->nb; ++k)
+      extra[bidx[k] - L.n_int_pad] = (int32_t)(L.npairs + (k - m->nb_int));
+    std::vector<int32_t> ptr(L.n_shared + 1), prs;
+    prs.reserve(L.npairs + (m->nb - m->nb_int));
+    for (int64_t sidx = 0; sidx < L.n_shared; ++sidx)
+    {
+      ptr[sidx] = (int32_t)prs.size();
+      for (int64_t k = L.sh_ptr[sidx]; k < L.sh_ptr[sidx + 1]; ++k)
+        prs.push_back((int32_t)L.sh_pairs[k]);
+      if (extra[sidx] >= 0)
+        prs.push_back(extra[sidx]);
+    }
+    ptr[L.n_shared] = (int32_t)prs.size();
+    FUSCHK(upload(m->allocs, &m->d_sh_ptr32, ptr, st));
+    FUSCHK(upload(m->allocs, &m->d_sh_pairs32, prs, st));
   }
   T *d_bsrc, *d_babs;
   FUSCHK(upload(m->allocs, &m->d_bidx, bidx, st));
@@ -777,52 +799,91 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
     else
       FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 1>(op, G, coef, ustage, b, S)));
   }
-  FUSCHK(shared_reduce<T>(op, b));
+  // boundary terms of the shared boundary dofs become one more partial each
+  hipStream_t st = m->ctx->stream;
+  const int64_t nbs = m->nb - m->nb_int;
+  if (nbs > 0)
+  {
+    ProfScope ps(m->ctx, "boundary");
+    hipLaunchKernelGGL((k_boundary_partial<T>), dim3(nblk(nbs)), dim3(256), 0, st, nbs,
+                       m->d_bidx + m->nb_int, static_cast<const T*>(m->d_bsrc) + m->nb_int,
+                       static_cast<const T*>(m->d_babs) + m->nb_int, S.gval,
+                       static_cast<const T*>(i == 0 ? m->v0 : m->vn),
+                       static_cast<T*>(op->d_partial) + op->L.npairs);
+  }
+  // interface dofs (held by other ranks too): reduce this rank's partials into b and pack them
+  const int64_t s0 = op->L.n_if_start_pad, s1 = op->L.n_shared;
+  if (s1 > s0)
+  {
+    ProfScope ps(m->ctx, "shared");
+    hipLaunchKernelGGL((k_shared_reduce<T, int32_t>), dim3(nblk(s1 - s0)), dim3(256), 0, st, s0, s1,
+                       m->d_sh_ptr32, m->d_sh_pairs32, static_cast<const T*>(op->d_partial),
+                       b + op->L.n_int_pad);
+  }
+  HIPCHK(hipGetLastError());
   return halo_pack<T>(op, b);
 }
 
-// Stage i, second half, shared dofs only: ordered sum of the sharers' partials, boundary terms,
-// the same fused update on the shared range of the internal vectors.
+// Stage i, second half, shared dofs only.  Rank-local shared dofs: fixed-order sum of the block
+// partials fused with the stage update (k_shared_stage).  Interface dofs: ordered sum of the
+// sharers' totals (halo_unpack) followed by k_stage on that index range.
 template <typename T>
 static int stage_end(fus_model* m, int i, double t, double dt)
 {
   fus_op* op = m->op;
   fus_ctx* c = m->ctx;
   hipStream_t st = c->stream;
-  const int64_t off = op->L.n_int_pad, n = op->L.n_internal - off;  // both multiples of 16
   const StageScalars sc = stage_scalars<T>(m, i, t, dt);
+  const T adt = (T)sc.adt, bdt = (T)sc.bdt;
   T *u0 = static_cast<T*>(m->u0), *v0 = static_cast<T*>(m->v0), *u_ = static_cast<T*>(m->u_),
     *v_ = static_cast<T*>(m->v_), *un = static_cast<T*>(m->un), *vn = static_cast<T*>(m->vn),
     *b = static_cast<T*>(m->b);
   const T* minv = static_cast<const T*>(m->minv);
-  FUSCHK(halo_unpack<T>(op, b));
-  const int64_t nbs = m->nb - m->nb_int;
-  if (nbs > 0)
-  {
-    ProfScope ps(c, "boundary");
-    hipLaunchKernelGGL((k_boundary<T>), dim3(nblk(nbs)), dim3(256), 0, st, nbs,
-                       m->d_bidx + m->nb_int, static_cast<const T*>(m->d_bsrc) + m->nb_int,
-                       static_cast<const T*>(m->d_babs) + m->nb_int, (T)sc.gval,
-                       (i == 0) ? v0 : vn, b);
-  }
-  if (n > 0)
+  const T* partial = static_cast<const T*>(op->d_partial);
+  const int64_t off = op->L.n_int_pad, nloc = op->L.n_shared_local;
+  if (nloc > 0)
   {
     ProfScope ps(c, "stage");
-    const unsigned grid = (unsigned)std::min<int64_t>(nblk(n / (16 / sizeof(T))), 256 * 16);
-    const T adt = (T)sc.adt, bdt = (T)sc.bdt;
+    const dim3 grid(nblk(nloc)), blk(256);
     switch (i)
     {
     case 0:
-      hipLaunchKernelGGL((k_stage<T, 0>), dim3(grid), dim3(256), 0, st, n, b + off, minv + off,
-                         vn + off, un + off, u0 + off, v0 + off, u_ + off, v_ + off, adt, bdt);
+      hipLaunchKernelGGL((k_shared_stage<T, 0>), grid, blk, 0, st, nloc, m->d_sh_ptr32,
+                         m->d_sh_pairs32, partial, minv + off, vn + off, un + off, u0 + off,
+                         v0 + off, u_ + off, v_ + off, adt, bdt);
       break;
     case 3:
-      hipLaunchKernelGGL((k_stage<T, 3>), dim3(grid), dim3(256), 0, st, n, b + off, minv + off,
-                         vn + off, un + off, u0 + off, v0 + off, u_ + off, v_ + off, adt, bdt);
+      hipLaunchKernelGGL((k_shared_stage<T, 3>), grid, blk, 0, st, nloc, m->d_sh_ptr32,
+                         m->d_sh_pairs32, partial, minv + off, vn + off, un + off, u0 + off,
+                         v0 + off, u_ + off, v_ + off, adt, bdt);
       break;
     default:
-      hipLaunchKernelGGL((k_stage<T, 1>), dim3(grid), dim3(256), 0, st, n, b + off, minv + off,
-                         vn + off, un + off, u0 + off, v0 + off, u_ + off, v_ + off, adt, bdt);
+      hipLaunchKernelGGL((k_shared_stage<T, 1>), grid, blk, 0, st, nloc, m->d_sh_ptr32,
+                         m->d_sh_pairs32, partial, minv + off, vn + off, un + off, u0 + off,
+                         v0 + off, u_ + off, v_ + off, adt, bdt);
+    }
+  }
+  if (op->L.n_shared > op->L.n_if_start_pad)
+  {
+    FUSCHK(halo_unpack<T>(op, b));
+    ProfScope ps(c, "stage");
+    // interface range of the internal vectors; start and length are multiples of 16
+    const int64_t o2 = off + op->L.n_if_start_pad;
+    const int64_t n2 = op->L.n_internal - o2;
+    const unsigned grid = (unsigned)std::min<int64_t>(nblk(n2 / (16 / sizeof(T))), 256 * 16);
+    switch (i)
+    {
+    case 0:
+      hipLaunchKernelGGL((k_stage<T, 0>), dim3(grid), dim3(256), 0, st, n2, b + o2, minv + o2,
+                         vn + o2, un + o2, u0 + o2, v0 + o2, u_ + o2, v_ + o2, adt, bdt);
+      break;
+    case 3:
+      hipLaunchKernelGGL((k_stage<T, 3>), dim3(grid), dim3(256), 0, st, n2, b + o2, minv + o2,
+                         vn + o2, un + o2, u0 + o2, v0 + o2, u_ + o2, v_ + o2, adt, bdt);
+      break;
+    default:
+      hipLaunchKernelGGL((k_stage<T, 1>), dim3(grid), dim3(256), 0, st, n2, b + o2, minv + o2,
+                         vn + o2, un + o2, u0 + o2, v0 + o2, u_ + o2, v_ + o2, adt, bdt);
     }
   }
   HIPCHK(hipGetLastError());
@@ -1359,10 +1420,11 @@ int fus_model_create(fus_ctx* c, int kind, fus_op* op, const void* c0, const voi
   int r = d_model_setup(m.get(), c0, rho0, nfacets, facet_cells, facet_local, facet_tags);
   if (r == FUS_OK && !c->local_group)
   {
-    // add the sharers' parts of m / src / abs over RCCL, then finish; with the in-process
-    // transport this happens in fus_group_finish_setup once every member exists
-    for (int k = 0; k < 3 && r == FUS_OK; ++k)
-      r = d_halo_sum(op, setup_halo_vector(m.get(), k));
+    // add the sharers' parts of the lumped mass over RCCL, then finish; with the in-process
+    // transport this happens in fus_group_finish_setup once every member exists.  The boundary
+    // weights of interface dofs stay per-rank: each rank adds the term of its own facets to its
+    // partial b and the exchange sums them (v_n is identical on all sharers).
+    r = d_halo_sum(op, setup_halo_vector(m.get(), 0));
     if (r == FUS_OK)
       r = d_setup_finish(m.get());
   }
@@ -1410,8 +1472,7 @@ int fus_group_finish_setup(fus_model** ms, int n)
 {
   if (!ms || n < 1)
     return fail(FUS_ERR_ARG, "bad group");
-  for (int k = 0; k < 3; ++k)
-    FUSCHK(group_halo(ms, n, k));
+  FUSCHK(group_halo(ms, n, 0));  // lumped mass only (see fus_model_create)
   for (int i = 0; i < n; ++i)
     FUSCHK(d_setup_finish(ms[i]));
   return FUS_OK;

@@ -521,19 +521,71 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     partial[sh_off + (l - sh.nint)] = y_l[l];
 }
 
-// bsh[s] = sum over the (block, slot) pairs of shared dof s, ascending block order
-template <typename T>
-__global__ void k_shared_reduce(int64_t n_shared, const int64_t* __restrict__ sh_ptr,
-                                const int64_t* __restrict__ sh_pairs,
-                                const T* __restrict__ partial, T* __restrict__ bsh)
+// bsh[s] = sum over the (block, slot) pairs of shared dof s, ascending block order (a trailing
+// pseudo pair carries the boundary term of a shared boundary dof, see k_boundary_partial)
+template <typename T, typename I>
+__global__ void k_shared_reduce(int64_t s0, int64_t s1, const I* __restrict__ sh_ptr,
+                                const I* __restrict__ sh_pairs, const T* __restrict__ partial,
+                                T* __restrict__ bsh)
 {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n_shared)
+  const int64_t s = s0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= s1)
     return;
   T acc = T(0);
-  for (int64_t k = sh_ptr[s]; k < sh_ptr[s + 1]; ++k)
+  for (I k = sh_ptr[s]; k < sh_ptr[s + 1]; ++k)
     acc += partial[sh_pairs[k]];
   bsh[s] = acc;
+}
+
+// Shared dofs of one rank: fixed-order sum of the partials fused with the RK4 stage update of
+// k_stage (same formulas); vectors are passed offset to the shared range.
+template <typename T, int STAGE>
+__global__ void __launch_bounds__(256)
+k_shared_stage(int64_t n, const int32_t* __restrict__ sh_ptr, const int32_t* __restrict__ sh_pairs,
+               const T* __restrict__ partial, const T* __restrict__ minv, T* __restrict__ vn,
+               T* __restrict__ un, T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ u_,
+               T* __restrict__ v_, T adt, T bdt)
+{
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n)
+    return;
+  T acc = T(0);
+  for (int32_t k = sh_ptr[s]; k < sh_ptr[s + 1]; ++k)
+    acc += partial[sh_pairs[k]];
+  const T kv = acc * minv[s];
+  if (STAGE == 0)
+  {
+    const T u = u0[s], v = v0[s];
+    u_[s] = v * bdt + u;
+    v_[s] = kv * bdt + v;
+    un[s] = v * adt + u;
+    vn[s] = kv * adt + v;
+  }
+  else if (STAGE == 3)
+  {
+    u0[s] = vn[s] * bdt + u_[s];
+    v0[s] = kv * bdt + v_[s];
+  }
+  else
+  {
+    const T w = vn[s];
+    u_[s] = w * bdt + u_[s];
+    v_[s] = kv * bdt + v_[s];
+    un[s] = w * adt + u0[s];
+    vn[s] = kv * adt + v0[s];
+  }
+}
+
+// Boundary term of shared boundary dofs, written as one more partial (summed last):
+// slot[k] = g(t) src[k] - abs[k] * v_stage[idx[k]]     (Linear.hpp:205; forms.py:38-39)
+template <typename T>
+__global__ void k_boundary_partial(int64_t nb, const int32_t* __restrict__ idx,
+                                   const T* __restrict__ srcw, const T* __restrict__ absw, T gval,
+                                   const T* __restrict__ vstage, T* __restrict__ slot)
+{
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nb)
+    slot[k] = gval * srcw[k] - absw[k] * vstage[idx[k]];
 }
 
 // Diagonal boundary terms (Linear.hpp:205 with forms.py:38-39 collocated at GLL nodes):

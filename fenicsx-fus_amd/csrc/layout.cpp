@@ -268,6 +268,40 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
     if (nblk[g] == 0)
       sh_id[g] = (int32_t)L.n_shared++;
 
+  // shared dofs held by other ranks too (interface dofs) go last in the shared range, so the
+  // rank-local shared dofs and the interface dofs are two contiguous index ranges
+  L.n_shared_local = L.n_shared;
+  L.n_if_start_pad = L.n_shared;
+  if (force_shared)
+  {
+    std::vector<int64_t> owner(L.n_shared, -1);
+    for (int64_t g = 0; g < ndofs; ++g)
+      if (sh_id[g] >= 0)
+        owner[sh_id[g]] = g;
+    int64_t nlocal = 0;
+    for (int64_t k = 0; k < L.n_shared; ++k)
+      if (!force_shared[owner[k]])
+        ++nlocal;
+    const int64_t nif = L.n_shared - nlocal;
+    if (nif > 0)
+    {
+      // the interface range starts on a 128-byte boundary (the slots in between stay empty)
+      const int64_t start = (nlocal + 15) & ~(int64_t)15;
+      std::vector<int32_t> remap(L.n_shared, -1);
+      int64_t cl = 0, ci = start;
+      for (int64_t k = 0; k < L.n_shared; ++k)
+        remap[k] = (int32_t)(force_shared[owner[k]] ? ci++ : cl++);
+      for (int64_t g = 0; g < ndofs; ++g)
+        if (sh_id[g] >= 0)
+          sh_id[g] = remap[sh_id[g]];
+      for (auto& v : pair_shid)
+        v = remap[v];
+      L.n_shared_local = nlocal;
+      L.n_if_start_pad = start;
+      L.n_shared = start + nif;
+    }
+  }
+
   L.n_int_pad = (int_cursor + 15) & ~(int64_t)15;
   L.npairs = L.blk_sh_off[L.nblocks];
   L.n_internal = (L.n_int_pad + L.n_shared + 15) & ~(int64_t)15;

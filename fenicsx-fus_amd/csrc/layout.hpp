@@ -48,6 +48,10 @@ struct Layout
   std::vector<int32_t> sh_gidx;       // [npairs] internal dof of each (block, shared slot)
   int64_t n_int_pad = 0;              // shared region starts here (multiple of 16)
   int64_t n_interior = 0, n_shared = 0, npairs = 0;
+  // shared slots [0, n_shared_local) are rank-local dofs; [n_if_start_pad, n_shared) are interface
+  // dofs (held by other ranks too); n_if_start_pad is a multiple of 16, slots in between are empty.
+  // n_shared counts slots (= dofs when there is no interface).
+  int64_t n_shared_local = 0, n_if_start_pad = 0;
   int64_t n_internal = 0;             // padded internal vector length (multiple of 16)
   std::vector<int64_t> sh_ptr;        // [n_shared+1] CSR: shared dof -> pair indices
   std::vector<int64_t> sh_pairs;      // [npairs] ascending block order

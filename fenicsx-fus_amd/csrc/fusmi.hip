@@ -124,6 +124,7 @@ struct fus_ctx
   int device = 0;
   hipStream_t stream = nullptr;
   int deterministic = 0;  // 1: conflict-free rounds (bitwise reproducible); 0: LDS atomics
+  int fields = 1;         // operator inputs per block pass the ops are sized for (2: Lossy)
   int block_elems = 32, waves = 4;  // measured best on MI355X at p=4 fp64 (profiles/r01_block_sweep.txt)
   bool prof = false;
   std::map<std::string, Prof> profs;
@@ -161,6 +162,7 @@ struct fus_op
   void *d_tmp_x = nullptr, *d_tmp_b = nullptr, *d_tmp_c = nullptr, *d_tmp_coef = nullptr;
   size_t lds_bytes = 0;
   int deterministic = 0;
+  int nfields = 1;
   // neighbours (multi-GPU)
   std::vector<Neigh> neigh;
   int32_t* d_uidx = nullptr;  // unique interface dofs (internal)
@@ -175,7 +177,8 @@ struct fus_model
   int kind;
   double freq, amp, speed;
   void *u0 = nullptr, *v0 = nullptr, *u_ = nullptr, *v_ = nullptr, *un = nullptr, *vn = nullptr,
-       *b = nullptr, *minv = nullptr, *m = nullptr, *coef = nullptr;
+       *b = nullptr, *minv = nullptr, *m = nullptr, *coef = nullptr, *coef2 = nullptr;
+  void* d_bsrc2 = nullptr;  // lossy: delta/(rho c^2) w_f on the source facets (dg term)
   // boundary dofs (diagonal source / absorbing weights), sorted by internal index:
   // [0, nb_int) are block-interior (applied in the fused epilogue through d_blk_bnd_off),
   // [nb_int, nb) are shared dofs (applied by k_boundary after the partial sums are reduced)
@@ -248,7 +251,7 @@ struct ProfScope
 // -------------------------------------------------------------------------------------------------
 // typed implementation
 // -------------------------------------------------------------------------------------------------
-template <typename T, int P, int OP, int ATOMIC, int STAGE>
+template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF>
 static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec,
                              const StageArgs<T>& S)
 {
@@ -259,11 +262,11 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
   static bool attr_set = false;  // per instantiation
   if (!attr_set)
   {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC, STAGE>), dim3(op->L.nblocks),
+  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC, STAGE, NF>), dim3(op->L.nblocks),
                      dim3(64 * op->L.waves), op->lds_bytes, op->ctx->stream, op->A, Dk,
                      static_cast<const T*>(op->d_Dg), geo, coef, x, bvec,
                      static_cast<T*>(op->d_partial), S);
@@ -271,12 +274,14 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
   return FUS_OK;
 }
 
-template <typename T, int P, int OP, int STAGE>
+template <typename T, int P, int OP, int STAGE, int NF = 1>
 static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec,
                            const StageArgs<T>& S)
 {
-  return op->deterministic ? launch_block_op_v<T, P, OP, 0, STAGE>(op, geo, coef, x, bvec, S)
-                           : launch_block_op_v<T, P, OP, 1, STAGE>(op, geo, coef, x, bvec, S);
+  if (NF > op->nfields)
+    return fail(FUS_ERR_STATE, "operator data was not created for two-field models (option fields=2)");
+  return op->deterministic ? launch_block_op_v<T, P, OP, 0, STAGE, NF>(op, geo, coef, x, bvec, S)
+                           : launch_block_op_v<T, P, OP, 1, STAGE, NF>(op, geo, coef, x, bvec, S);
 }
 
 template <typename T>
@@ -453,7 +458,7 @@ static int op_setup_device(fus_op* op)
   op->A.lds_nloc = (L.max_nloc + 1) & ~1;
   op->A.waves = L.waves;
   op->A.lds_nelem = (L.max_nelem + 7) & ~7;
-  op->lds_bytes = L.lds_bytes(sizeof(T));
+  op->lds_bytes = L.lds_bytes(sizeof(T), op->nfields);
   if (op->lds_bytes > 160 * 1024)
     return fail(FUS_ERR_LIMIT, "block does not fit 160 KB of LDS; lower block_elems");
 
@@ -603,8 +608,8 @@ static void facet_diag_host(const fus_op* op, int64_t nfacets, const int32_t* fc
 }
 
 template <typename T, int P>
-static int model_setup(fus_model* m, const void* c0_, const void* rho0_, int64_t nfacets,
-                       const int32_t* fc, const int32_t* fl, const int32_t* ft)
+static int model_setup(fus_model* m, const void* c0_, const void* rho0_, const void* delta0_,
+                       int64_t nfacets, const int32_t* fc, const int32_t* fl, const int32_t* ft)
 {
   fus_op* op = m->op;
   fus_ctx* c = m->ctx;
@@ -613,23 +618,29 @@ static int model_setup(fus_model* m, const void* c0_, const void* rho0_, int64_t
   const int64_t n = L.n_internal;
   const T* c0 = static_cast<const T*>(c0_);
   const T* rho0 = static_cast<const T*>(rho0_);
+  const T* delta0 = static_cast<const T*>(delta0_);
+  const bool lossy = m->kind == FUS_LOSSY;
   auto& pool = m->allocs;
   for (void** v : {&m->u0, &m->v0, &m->u_, &m->v_, &m->un, &m->vn, &m->b, &m->minv, &m->m})
     FUSCHK(dalloc_bytes(pool, v, n * sizeof(T), true, st));
 
-  // operator coefficient -1/rho (Linear.hpp:154-155) and mass coefficient 1/(rho c^2)
-  // (forms.py:36), internal element order
-  std::vector<T> coef(op->ncells), mcoef(op->ncells);
+  // operator coefficients -1/rho (Linear.hpp:154-155) [and -delta/(rho c^2), Lossy.hpp:166-169]
+  // and the mass coefficient 1/(rho c^2) (forms.py:36), internal element order
+  std::vector<T> coef(op->ncells), coef2(lossy ? op->ncells : 0), mcoef(op->ncells);
   for (int64_t e = 0; e < op->ncells; ++e)
   {
     const int64_t cell = L.cell_perm[e];
     coef[e] = T(-1.0) / rho0[cell];
+    if (lossy)
+      coef2[e] = -delta0[cell] / rho0[cell] / c0[cell] / c0[cell];
     mcoef[e] = T(1.0) / rho0[cell] / c0[cell] / c0[cell];
   }
-  T *d_coef, *d_mcoef;
+  T *d_coef, *d_coef2 = nullptr, *d_mcoef;
   FUSCHK(upload(pool, &d_coef, coef, st));
+  if (lossy)
+    FUSCHK(upload(pool, &d_coef2, coef2, st));
   FUSCHK(upload(pool, &d_mcoef, mcoef, st));
-  m->coef = d_coef;
+  m->coef = d_coef, m->coef2 = d_coef2;
 
   // lumped mass, this rank's cells only: m = M(1/(rho c^2)) 1  (Linear.hpp:127-133)
   T* ones = static_cast<T*>(m->un);
@@ -637,11 +648,24 @@ static int model_setup(fus_model* m, const void* c0_, const void* rho0_, int64_t
   FUSCHK((apply_internal<T, P, OP_MASS>(op, d_mcoef, ones, static_cast<T*>(m->m))));
   HIPCHK(hipMemsetAsync(m->un, 0, n * sizeof(T), st));
 
-  // boundary weights of this rank's facets: tag 1 -> (1/rho) w_f, tag 2 -> (1/(rho c)) w_f
-  // (forms.py:38-39), as full internal vectors until the sharers' parts have been added
-  std::vector<T> src(op->ndofs, T(0)), absb(op->ndofs, T(0)), cs(op->ncells), ca(op->ncells);
+  // boundary weights of this rank's facets (diagonal: GLL collocation)
+  //   Linear (SC1-BM1/forms.py:38-39): src = (1/rho) w_f on tag 1, abs = (1/(rho c)) w_f on tag 2
+  //   Lossy  (BM7-SC1/forms.py:37-42): abs on EVERY boundary facet, src2 = (delta/(rho c^2)) w_f on
+  //   tag 1 (dg term) and the mass gains (delta/(rho c^3)) w_f on every boundary facet
+  std::vector<T> src(op->ndofs, T(0)), absb(op->ndofs, T(0)), src2, mb;
+  std::vector<T> cs(op->ncells), ca(op->ncells), cs2, cm;
   for (int64_t k = 0; k < op->ncells; ++k)
     cs[k] = T(1.0) / rho0[k], ca[k] = T(1.0) / rho0[k] / c0[k];
+  if (lossy)
+  {
+    src2.assign(op->ndofs, T(0)), mb.assign(op->ndofs, T(0));
+    cs2.resize(op->ncells), cm.resize(op->ncells);
+    for (int64_t k = 0; k < op->ncells; ++k)
+    {
+      cs2[k] = delta0[k] / rho0[k] / c0[k] / c0[k];
+      cm[k] = delta0[k] / rho0[k] / c0[k] / c0[k] / c0[k];
+    }
+  }
   std::vector<int32_t> c1, l1, c2, l2;
   for (int64_t f = 0; f < nfacets; ++f)
   {
@@ -649,21 +673,34 @@ static int model_setup(fus_model* m, const void* c0_, const void* rho0_, int64_t
       return fail(FUS_ERR_ARG, "facet (cell, local facet) out of range");
     if (ft[f] == 1)
       c1.push_back(fc[f]), l1.push_back(fl[f]);
-    else if (ft[f] == 2)
-      c2.push_back(fc[f]), l2.push_back(fl[f]);
+    if (lossy || ft[f] == 2)
+      c2.push_back(fc[f]), l2.push_back(fl[f]);   // lossy: plain ds = every listed facet
   }
   facet_diag_host<T>(op, (int64_t)c1.size(), c1.data(), l1.data(), cs.data(), src.data());
   facet_diag_host<T>(op, (int64_t)c2.size(), c2.data(), l2.data(), ca.data(), absb.data());
+  if (lossy)
+  {
+    facet_diag_host<T>(op, (int64_t)c1.size(), c1.data(), l1.data(), cs2.data(), src2.data());
+    facet_diag_host<T>(op, (int64_t)c2.size(), c2.data(), l2.data(), cm.data(), mb.data());
+  }
   T* tmpc = static_cast<T*>(op->d_tmp_c);
-  void* dst[2] = {m->u_, m->v_};  // scratch until fus_model_init: full-length src / abs weights
-  std::vector<T>* hv[2] = {&src, &absb};
-  for (int k = 0; k < 2; ++k)
+  // scratch until fus_model_init: full-length src / abs / src2 weights; b holds the mass term
+  void* dst[4] = {m->u_, m->v_, m->vn, m->b};
+  std::vector<T>* hv[4] = {&src, &absb, &src2, &mb};
+  for (int k = 0; k < (lossy ? 4 : 2); ++k)
   {
     HIPCHK(hipMemcpyAsync(tmpc, hv[k]->data(), op->ndofs * sizeof(T), hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL((k_to_internal<T>), dim3(nblk(op->ndofs)), dim3(256), 0, st, op->ndofs,
                        op->d_dof_perm, tmpc, static_cast<T*>(dst[k]));
     HIPCHK(hipStreamSynchronize(st));
   }
+  if (lossy)
+  {
+    hipLaunchKernelGGL((k_add_vec<T>), dim3(1024), dim3(256), 0, st, n, static_cast<const T*>(m->b),
+                       static_cast<T*>(m->m));
+    HIPCHK(hipMemsetAsync(m->b, 0, n * sizeof(T), st));
+  }
+  HIPCHK(hipGetLastError());
   return FUS_OK;
 }
 
@@ -679,18 +716,23 @@ static int model_setup_finish(fus_model* m)
   const int64_t n = op->L.n_internal;
   hipLaunchKernelGGL((k_reciprocal<T>), dim3(nblk(n)), dim3(256), 0, st, n,
                      static_cast<const T*>(m->m), static_cast<T*>(m->minv));
-  std::vector<T> src(n), absb(n);
+  const bool lossy = m->kind == FUS_LOSSY;
+  std::vector<T> src(n), absb(n), src2(lossy ? n : 0);
   HIPCHK(hipMemcpyAsync(src.data(), m->u_, n * sizeof(T), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(absb.data(), m->v_, n * sizeof(T), hipMemcpyDeviceToHost, st));
+  if (lossy)
+    HIPCHK(hipMemcpyAsync(src2.data(), m->vn, n * sizeof(T), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
   std::vector<int32_t> bidx;
-  std::vector<T> bsrc, babs;
+  std::vector<T> bsrc, babs, bsrc2;
   for (int64_t i = 0; i < n; ++i)
-    if (src[i] != T(0) || absb[i] != T(0))
+    if (src[i] != T(0) || absb[i] != T(0) || (lossy && src2[i] != T(0)))
     {
       bidx.push_back((int32_t)i);
       bsrc.push_back(src[i]);
       babs.push_back(absb[i]);
+      if (lossy)
+        bsrc2.push_back(src2[i]);
     }
   m->nb = (int64_t)bidx.size();
   {
@@ -728,8 +770,15 @@ static int model_setup_finish(fus_model* m)
   FUSCHK(upload(m->allocs, &d_bsrc, bsrc, st));
   FUSCHK(upload(m->allocs, &d_babs, babs, st));
   m->d_bsrc = d_bsrc, m->d_babs = d_babs;
+  if (lossy)
+  {
+    T* d_bsrc2;
+    FUSCHK(upload(m->allocs, &d_bsrc2, bsrc2, st));
+    m->d_bsrc2 = d_bsrc2;
+  }
   HIPCHK(hipMemsetAsync(m->u_, 0, n * sizeof(T), st));
   HIPCHK(hipMemsetAsync(m->v_, 0, n * sizeof(T), st));
+  HIPCHK(hipMemsetAsync(m->vn, 0, n * sizeof(T), st));
   HIPCHK(hipStreamSynchronize(st));
   m->setup_done = true;
   return FUS_OK;
@@ -737,7 +786,7 @@ static int model_setup_finish(fus_model* m)
 
 struct StageScalars
 {
-  double gval, adt, bdt;
+  double gval, dgval, adt, bdt;
 };
 
 // source scalar g(t_n) (Linear.hpp:185-192) and the stage's axpy factors (:282-294), in T
@@ -752,13 +801,28 @@ static StageScalars stage_scalars(const fus_model* m, int i, double t_, double d
   const T w0 = (T)(2 * M_PI * m->freq);
   const T period = (T)(1.0 / m->freq), window_length = (T)4.0;
   const T tn = t + c_runge[i] * dt;
-  T window;
+  T window, dwindow;
   if (tn < period * window_length)
+  {
     window = (T)(0.5 * (1.0 - std::cos((double)(freq * (T)M_PI * tn / window_length))));
+    dwindow = (T)(0.5 * M_PI) * freq / window_length
+              * (T)std::sin((double)(freq * (T)M_PI * tn / window_length));
+  }
   else
-    window = 1.0;
+    window = 1.0, dwindow = 0.0;
   StageScalars sc;
-  sc.gval = (double)(window * p0 * w0 / s0 * (T)std::cos((double)(w0 * tn)));
+  if (m->kind == FUS_LOSSY)
+  {
+    // heterogeneous-domain scaling, live in Lossy.hpp:216-220 (factor 2) and its derivative dg
+    sc.gval = (double)(window * (T)2.0 * p0 * w0 / s0 * (T)std::cos((double)(w0 * tn)));
+    sc.dgval = (double)(dwindow * (T)2.0 * p0 * w0 / s0 * (T)std::cos((double)(w0 * tn))
+                        - window * (T)2.0 * p0 * w0 * w0 / s0 * (T)std::sin((double)(w0 * tn)));
+  }
+  else
+  {
+    sc.gval = (double)(window * p0 * w0 / s0 * (T)std::cos((double)(w0 * tn)));  // Linear.hpp:192
+    sc.dgval = 0.0;
+  }
   sc.adt = (double)(dt * a_runge[i + 1]);
   sc.bdt = (double)(dt * b_runge[i]);
   return sc;
@@ -775,6 +839,8 @@ static StageArgs<T> stage_args(fus_model* m, const StageScalars& sc)
   S.adt = (T)sc.adt, S.bdt = (T)sc.bdt, S.gval = (T)sc.gval;
   S.blk_bnd_off = m->d_blk_bnd_off, S.bnd_idx = m->d_bidx;
   S.bnd_src = static_cast<const T*>(m->d_bsrc), S.bnd_abs = static_cast<const T*>(m->d_babs);
+  S.x2 = nullptr, S.coef2 = static_cast<const T*>(m->coef2);
+  S.bnd_src2 = static_cast<const T*>(m->d_bsrc2), S.dgval = (T)sc.dgval;
   return S;
 }
 
@@ -787,12 +853,22 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
   fus_op* op = m->op;
   const T* ustage = static_cast<const T*>(i == 0 ? m->u0 : m->un);  // a_0 = 0: un == u0
   T* b = static_cast<T*>(m->b);
-  const StageArgs<T> S = stage_args<T>(m, stage_scalars<T>(m, i, t, dt));
+  StageArgs<T> S = stage_args<T>(m, stage_scalars<T>(m, i, t, dt));
+  S.x2 = static_cast<const T*>(i == 0 ? m->v0 : m->vn);   // lossy: second operator input v_n
   const T* G = static_cast<const T*>(op->d_G);
   const T* coef = static_cast<const T*>(m->coef);
   {
     ProfScope ps(m->ctx, "stiffness");
-    if (i == 0)
+    if (m->kind == FUS_LOSSY)
+    {
+      if (i == 0)
+        FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 0, 2>(op, G, coef, ustage, b, S)));
+      else if (i == 3)
+        FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 3, 2>(op, G, coef, ustage, b, S)));
+      else
+        FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 1, 2>(op, G, coef, ustage, b, S)));
+    }
+    else if (i == 0)
       FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 0>(op, G, coef, ustage, b, S)));
     else if (i == 3)
       FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 3>(op, G, coef, ustage, b, S)));
@@ -808,6 +884,7 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
     hipLaunchKernelGGL((k_boundary_partial<T>), dim3(nblk(nbs)), dim3(256), 0, st, nbs,
                        m->d_bidx + m->nb_int, static_cast<const T*>(m->d_bsrc) + m->nb_int,
                        static_cast<const T*>(m->d_babs) + m->nb_int, S.gval,
+                       m->d_bsrc2 ? static_cast<const T*>(m->d_bsrc2) + m->nb_int : nullptr, S.dgval,
                        static_cast<const T*>(i == 0 ? m->v0 : m->vn),
                        static_cast<T*>(op->d_partial) + op->L.npairs);
   }
@@ -980,10 +1057,10 @@ static int d_op_get_geometry(fus_op* op, void* G, void* dJ)
 {
   FUS_DISPATCH(op->dtype, op->P, (op_get_geometry<TT, PP>(op, G, dJ)));
 }
-static int d_model_setup(fus_model* m, const void* c0, const void* rho0, int64_t nf,
-                         const int32_t* fc, const int32_t* fl, const int32_t* ft)
+static int d_model_setup(fus_model* m, const void* c0, const void* rho0, const void* delta0,
+                         int64_t nf, const int32_t* fc, const int32_t* fl, const int32_t* ft)
 {
-  FUS_DISPATCH(m->op->dtype, m->op->P, (model_setup<TT, PP>(m, c0, rho0, nf, fc, fl, ft)));
+  FUS_DISPATCH(m->op->dtype, m->op->P, (model_setup<TT, PP>(m, c0, rho0, delta0, nf, fc, fl, ft)));
 }
 static int d_model_step(fus_model* m, double t, double dt)
 {
@@ -1041,7 +1118,7 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   {
     std::string err = build_layout(op->L, op->P, op->ncells, op->ndofs, op->h_dofmap.data(),
                                    cen.data(), be, c->waves, force_shared);
-    const bool too_big = err.empty() ? op->L.lds_bytes(op->ts) + 64 > 160 * 1024
+    const bool too_big = err.empty() ? op->L.lds_bytes(op->ts, op->nfields) + 64 > 160 * 1024
                                      : err.find("65535") != std::string::npos;
     if (too_big && be > 1)
       continue;
@@ -1126,6 +1203,12 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
   }
   else if (!strcmp(key, "deterministic"))
     c->deterministic = value != 0;
+  else if (!strcmp(key, "fields"))
+  {
+    if (value != 1 && value != 2)
+      return fail(FUS_ERR_ARG, "fields must be 1 or 2");
+    c->fields = (int)value;
+  }
   else
     return fail(FUS_ERR_ARG, std::string("unknown option ") + key);
   return FUS_OK;
@@ -1219,6 +1302,7 @@ int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_
   HIPCHK(hipSetDevice(c->device));
   std::unique_ptr<fus_op> op(new fus_op());
   op->deterministic = c->deterministic;
+  op->nfields = c->fields;
   op->ctx = c, op->P = P, op->N = N, op->Nd = N * N * N, op->dtype = dtype;
   op->ts = dtype == FUS_F64 ? 8 : 4;
   op->ncells = ncells, op->ndofs = ndofs, op->nnodes = nnodes;
@@ -1406,10 +1490,14 @@ int fus_model_create(fus_ctx* c, int kind, fus_op* op, const void* c0, const voi
 {
   if (!c || !op || !c0 || !rho0 || !out)
     return fail(FUS_ERR_ARG, "null argument");
-  if (kind != FUS_LINEAR)
-    return fail(FUS_ERR_ARG, "only FUS_LINEAR is implemented");
-  if (delta0 || beta0)
+  if (kind != FUS_LINEAR && kind != FUS_LOSSY)
+    return fail(FUS_ERR_ARG, "only FUS_LINEAR and FUS_LOSSY are implemented");
+  if (kind == FUS_LINEAR && (delta0 || beta0))
     return fail(FUS_ERR_ARG, "delta0/beta0 must be NULL for FUS_LINEAR");
+  if (kind == FUS_LOSSY && (!delta0 || beta0))
+    return fail(FUS_ERR_ARG, "FUS_LOSSY needs delta0 (and no beta0)");
+  if (kind == FUS_LOSSY && op->nfields < 2)
+    return fail(FUS_ERR_STATE, "FUS_LOSSY needs operator data created with option fields=2");
   if (nfacets > 0 && (!facet_cells || !facet_local || !facet_tags))
     return fail(FUS_ERR_ARG, "null facet arrays");
   if (!(freq > 0) || !(speed > 0))
@@ -1417,7 +1505,7 @@ int fus_model_create(fus_ctx* c, int kind, fus_op* op, const void* c0, const voi
   HIPCHK(hipSetDevice(c->device));
   std::unique_ptr<fus_model> m(new fus_model());
   m->ctx = c, m->op = op, m->kind = kind, m->freq = freq, m->amp = amp, m->speed = speed;
-  int r = d_model_setup(m.get(), c0, rho0, nfacets, facet_cells, facet_local, facet_tags);
+  int r = d_model_setup(m.get(), c0, rho0, delta0, nfacets, facet_cells, facet_local, facet_tags);
   if (r == FUS_OK && !c->local_group)
   {
     // add the sharers' parts of the lumped mass over RCCL, then finish; with the in-process

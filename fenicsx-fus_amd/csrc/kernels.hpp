@@ -59,6 +59,12 @@ struct StageArgs
   const int32_t* bnd_idx;
   const T* bnd_src;
   const T* bnd_abs;
+  // second operator input (NF == 2, lossy model: K(coef) x + K(coef2) x2, Lossy.hpp:231-232) and
+  // the dg source term (BM7-SC1/forms.py:42)
+  const T* x2;
+  const T* coef2;
+  const T* bnd_src2;
+  T dgval;
 };
 
 enum
@@ -150,13 +156,14 @@ __device__ __forceinline__ void elem_fetch(ElemIn<T, N, OP>& in, int er, const T
 // One element's operator action, accumulated into the block's LDS vector y_l.
 // ATOMIC: the accumulation is an LDS floating-point atomic (ds_add_f64 / ds_add_f32), so waves need
 // not proceed in conflict-free rounds; otherwise a plain read-modify-write (deterministic).
-template <typename T, int N, int OP, int ATOMIC>
+template <typename T, int N, int OP, int ATOMIC, int NF>
 __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP>& in, const DTab<T, N>& Dk,
                                              const T (&Drb)[N], const T (&Drc)[N], const T (&Dcb)[N],
                                              const T (&Dcc)[N], const T* __restrict__ x_l,
                                              T* __restrict__ y_l, T* __restrict__ sA,
                                              T* __restrict__ sB, const uint16_t* __restrict__ ldm_l,
-                                             const T* __restrict__ cf_l, int p, int b, int c)
+                                             const T* __restrict__ cf_l, const T* __restrict__ x2_l,
+                                             const T* __restrict__ cf2_l, int p, int b, int c)
 {
   constexpr int N2 = N * N, Nd = N * N * N;
   constexpr int VW = GLoad<T, N>::VW;
@@ -166,7 +173,9 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP>& in, const D
 #pragma unroll
   for (int a = 0; a < N; ++a)
     li[a] = ldm_l[in.er * Nd + a * N2 + p];
-  const T cf = cf_l[in.er];
+  // NF == 2: the element input is coef x + coef2 x2 (both operators share G, the action is linear)
+  // and the transform coefficient becomes 1
+  const T cf = (NF == 2) ? T(1) : cf_l[in.er];
   T Y[N];
 #if defined(FUS_ABLATE) && FUS_ABLATE == 1  // timing experiment: loads only, no contractions
   if (OP == OP_STIFFNESS)
@@ -189,9 +198,19 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP>& in, const D
   if (OP == OP_STIFFNESS)
   {
     T X[N], F0[N], F1[N], F2[N];
+    if (NF == 2)
+    {
+      const T c1 = cf_l[in.er], c2 = cf2_l[in.er];
 #pragma unroll
-    for (int a = 0; a < N; ++a)
-      X[a] = x_l[li[a]];
+      for (int a = 0; a < N; ++a)
+        X[a] = c1 * x_l[li[a]] + c2 * x2_l[li[a]];
+    }
+    else
+    {
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        X[a] = x_l[li[a]];
+    }
     // derivative along tensor index 0: registers only (spectral_op.hpp:194-196)
 #pragma unroll
     for (int q = 0; q < N; ++q)
@@ -289,7 +308,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP>& in, const D
 // :203-221): for the block's interior dofs the sum in LDS is complete, so b never goes to HBM --
 // boundary terms are added in LDS, kv = b * minv, and u_, v_, un', vn' (or the new u0, v0 at stage 3)
 // are written straight from here.  Shared dofs still leave as partial sums.
-template <typename T, int P, int OP, int ATOMIC, int STAGE>
+template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF>
 __global__ void __launch_bounds__(256)
 k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
            const T* __restrict__ geo, const T* __restrict__ coef, const T* __restrict__ x,
@@ -301,10 +320,12 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   extern __shared__ __align__(16) unsigned char smem_raw[];
   T* x_l = reinterpret_cast<T*>(smem_raw);
   T* y_l = x_l + A.lds_nloc;
-  T* scratch = y_l + A.lds_nloc;
+  T* x2_l = y_l + A.lds_nloc;                               // second input (NF == 2 only)
+  T* scratch = x2_l + (NF == 2 ? A.lds_nloc : 0);
   T* D_l = scratch + (size_t)A.waves * EPW * 2 * Nd;      // derivative table
-  T* cf_l = D_l + N2;                                       // per-element coefficient
-  uint16_t* ldm_l = reinterpret_cast<uint16_t*>(cf_l + A.lds_nelem);  // local dofmaps (16-B aligned)
+  T* cf_l = D_l + N2;                                       // per-element coefficient(s)
+  T* cf2_l = cf_l + A.lds_nelem;
+  uint16_t* ldm_l = reinterpret_cast<uint16_t*>(cf2_l + (NF == 2 ? A.lds_nelem : 0));  // 16-B aligned
   int16_t* rt_l = reinterpret_cast<int16_t*>(ldm_l + (size_t)A.lds_nelem * Nd);
 
   const int blk = blockIdx.x;
@@ -347,25 +368,34 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     typedef T V2 __attribute__((ext_vector_type(2)));
     constexpr int UN = 8;
     const V2* xg = reinterpret_cast<const V2*>(x + int_off);  // int_off is a multiple of 16
+    const V2* xg2 = reinterpret_cast<const V2*>((NF == 2 ? S.x2 : x) + int_off);
     const int nvec = sh.nint >> 1;
     for (int base = tid; base < nvec; base += nthr * UN)
     {
-      V2 v[UN];
+      V2 v[UN], v2[UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u)
         if (base + u * nthr < nvec)
+        {
           v[u] = xg[base + u * nthr];
+          if (NF == 2)
+            v2[u] = xg2[base + u * nthr];
+        }
 #pragma unroll
       for (int u = 0; u < UN; ++u)
         if (base + u * nthr < nvec)
         {
           reinterpret_cast<V2*>(x_l)[base + u * nthr] = v[u];
+          if (NF == 2)
+            reinterpret_cast<V2*>(x2_l)[base + u * nthr] = v2[u];
           reinterpret_cast<V2*>(y_l)[base + u * nthr] = V2(T(0));
         }
     }
     if (tid == 0 && (sh.nint & 1))
     {
       x_l[sh.nint - 1] = x[int_off + sh.nint - 1];
+      if (NF == 2)
+        x2_l[sh.nint - 1] = S.x2[int_off + sh.nint - 1];
       y_l[sh.nint - 1] = T(0);
     }
     const int nsh = sh.nloc - sh.nint;
@@ -373,18 +403,24 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     for (int base = tid; base < nsh; base += nthr * UN)
     {
       int gi[UN];
-      T v[UN];
+      T v[UN], v2[UN];
 #pragma unroll
       for (int u = 0; u < UN; ++u)
         gi[u] = (base + u * nthr < nsh) ? gix[base + u * nthr] : 0;
 #pragma unroll
       for (int u = 0; u < UN; ++u)
+      {
         v[u] = x[gi[u]];
+        if (NF == 2)
+          v2[u] = S.x2[gi[u]];
+      }
 #pragma unroll
       for (int u = 0; u < UN; ++u)
         if (base + u * nthr < nsh)
         {
           x_l[sh.nint + base + u * nthr] = v[u];
+          if (NF == 2)
+            x2_l[sh.nint + base + u * nthr] = v2[u];
           y_l[sh.nint + base + u * nthr] = T(0);
         }
     }
@@ -401,7 +437,11 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
         reinterpret_cast<U4*>(ldm_l)[k] = src[k];
     }
     for (int k = tid; k < sh.nelem; k += nthr)
+    {
       cf_l[k] = coef[elem_off + k];
+      if (NF == 2)
+        cf2_l[k] = S.coef2[elem_off + k];
+    }
     if (tid < N2)
       D_l[tid] = Dg[tid];
   }
@@ -426,13 +466,13 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   {
     const bool has1 = r + 1 < ntrips;
     elem_fetch<T, N, OP>(inB, elem_of(r + 1), geo, elem_off, p);
-    elem_compute<T, N, OP, ATOMIC>(inA, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, p, b, c);
+    elem_compute<T, N, OP, ATOMIC, NF>(inA, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, x2_l, cf2_l, p, b, c);
     if (!ATOMIC && A.waves > 1)
       __syncthreads();
     elem_fetch<T, N, OP>(inA, elem_of(r + 2), geo, elem_off, p);
     if (has1)
     {
-      elem_compute<T, N, OP, ATOMIC>(inB, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, p, b, c);
+      elem_compute<T, N, OP, ATOMIC, NF>(inB, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, x2_l, cf2_l, p, b, c);
       if (!ATOMIC && A.waves > 1)
         __syncthreads();
     }
@@ -461,7 +501,10 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
       for (int k = k0 + tid; k < k1; k += nthr)
       {
         const int gi = S.bnd_idx[k];
-        y_l[gi - int_off] += S.gval * S.bnd_src[k] - S.bnd_abs[k] * vstage[gi];
+        T add = S.gval * S.bnd_src[k] - S.bnd_abs[k] * vstage[gi];
+        if (NF == 2)
+          add += S.dgval * S.bnd_src2[k];
+        y_l[gi - int_off] += add;
       }
       __syncthreads();
     }
@@ -581,11 +624,17 @@ k_shared_stage(int64_t n, const int32_t* __restrict__ sh_ptr, const int32_t* __r
 template <typename T>
 __global__ void k_boundary_partial(int64_t nb, const int32_t* __restrict__ idx,
                                    const T* __restrict__ srcw, const T* __restrict__ absw, T gval,
+                                   const T* __restrict__ src2w, T dgval,
                                    const T* __restrict__ vstage, T* __restrict__ slot)
 {
   const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k < nb)
-    slot[k] = gval * srcw[k] - absw[k] * vstage[idx[k]];
+  {
+    T v = gval * srcw[k] - absw[k] * vstage[idx[k]];
+    if (src2w)
+      v += dgval * src2w[k];
+    slot[k] = v;
+  }
 }
 
 // Diagonal boundary terms (Linear.hpp:205 with forms.py:38-39 collocated at GLL nodes):
@@ -736,6 +785,15 @@ __global__ void k_fill(int64_t n, T* __restrict__ x, T v)
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x)
     x[i] = v;
+}
+
+// y += x
+template <typename T>
+__global__ void k_add_vec(int64_t n, const T* __restrict__ x, T* __restrict__ y)
+{
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    y[i] += x[i];
 }
 
 // minv = 1/m where m != 0 (padding slots stay 0)

@@ -57,12 +57,13 @@ struct Layout
   std::vector<int64_t> sh_pairs;      // [npairs] ascending block order
   int32_t max_nloc = 0, max_rounds = 0, max_nelem = 0;
 
-  size_t lds_bytes(size_t sizeofT) const
+  // nfields: operator inputs staged per block (1: Linear; 2: Lossy, K(c1) u + K(c2) v in one pass)
+  size_t lds_bytes(size_t sizeofT, int nfields = 1) const
   {
     const size_t ne = ((size_t)max_nelem + 7) & ~(size_t)7;
-    return (size_t)2 * ((max_nloc + 1) & ~1) * sizeofT   // x_l, y_l
+    return (size_t)(1 + nfields) * ((max_nloc + 1) & ~1) * sizeofT   // x_l (, x2_l), y_l
            + (size_t)slots * 2 * Nd * sizeofT            // per-element exchange tiles
-           + (size_t)N * N * sizeofT + ne * sizeofT      // derivative table, coefficients
+           + (size_t)N * N * sizeofT + nfields * ne * sizeofT  // derivative table, coefficients
            + ne * Nd * 2                                 // local dofmaps
            + (size_t)max_rounds * slots * 2 + 16;        // round table
   }

@@ -17,30 +17,29 @@ from .mesh import Function, FunctionSpace
 from .operators import SpectralOperatorData, _array
 
 
-class LinearSpectralExplicit:
-    """``LinearSpectralExplicit(mesh, meshtags, k, c0, rho0, freq0, p0, s0, rk_order, dt)``
-    (_linear.py:267).  ``meshtags`` carries boundary facets as (cell, local facet) pairs with
-    ``values`` 1 = source, 2 = absorbing (what ``compute_integration_domains`` yields for the
-    tagged facets, Linear.hpp:113-118)."""
+class _SpectralExplicit:
+    """Shared host side of the offloaded explicit models (constructor plumbing, init, rk)."""
 
-    def __init__(self, mesh, meshtags, k, c0, rho0, freq0, p0, s0, rk_order=4, dt=None, V=None,
-                 ctx: Context | None = None):
+    _kind = _abi.FUS_LINEAR
+
+    def _create(self, mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt, V, ctx):
         if rk_order != 4:
             raise _abi.FusError("only the classical RK4 scheme (rk_order=4) is offloaded")
         self.mesh, self.dt = mesh, dt
         self.freq, self.p0, self.s0 = float(freq0), float(p0), float(s0)
         self.V = V or FunctionSpace(mesh, k)
-        self.data = SpectralOperatorData(self.V, ctx)
+        self.data = SpectralOperatorData(self.V, ctx, fields=2 if delta0 is not None else 1)
         self.ctx = self.data.ctx
         dt_ = self.data.dtype
         c0a = np.ascontiguousarray(_array(c0), dtype=dt_)
         rhoa = np.ascontiguousarray(_array(rho0), dtype=dt_)
+        dla = None if delta0 is None else np.ascontiguousarray(_array(delta0), dtype=dt_)
         cells = np.ascontiguousarray(meshtags.cells, dtype=np.int32)
         lf = np.ascontiguousarray(meshtags.local_facets, dtype=np.int32)
         tags = np.ascontiguousarray(meshtags.values, dtype=np.int32)
         self.h = C.c_void_p()
-        check(lib().fus_model_create(self.ctx.h, C.c_int(_abi.FUS_LINEAR), self.data.h, ptr(c0a), ptr(rhoa),
-                                     None, None, C.c_int64(len(cells)), ptr(cells), ptr(lf), ptr(tags),
+        check(lib().fus_model_create(self.ctx.h, C.c_int(self._kind), self.data.h, ptr(c0a), ptr(rhoa),
+                                     ptr(dla), None, C.c_int64(len(cells)), ptr(cells), ptr(lf), ptr(tags),
                                      C.c_double(self.freq), C.c_double(self.p0), C.c_double(self.s0),
                                      C.byref(self.h)))
         self.u_n = Function(self.V, dt_)
@@ -97,6 +96,36 @@ class LinearSpectralExplicit:
         if self.h:
             lib().fus_model_destroy(self.h)
             self.h = C.c_void_p()
+
+
+class LinearSpectralExplicit(_SpectralExplicit):
+    """``LinearSpectralExplicit(mesh, meshtags, k, c0, rho0, freq0, p0, s0, rk_order, dt)``
+    (_linear.py:267).  ``meshtags`` carries boundary facets as (cell, local facet) pairs with
+    ``values`` 1 = source, 2 = absorbing (what ``compute_integration_domains`` yields for the
+    tagged facets, Linear.hpp:113-118)."""
+
+    _kind = _abi.FUS_LINEAR
+
+    def __init__(self, mesh, meshtags, k, c0, rho0, freq0, p0, s0, rk_order=4, dt=None, V=None,
+                 ctx: Context | None = None):
+        self._create(mesh, meshtags, k, c0, rho0, None, freq0, p0, s0, rk_order, dt, V, ctx)
+
+
+class LossySpectralExplicit(_SpectralExplicit):
+    """``LossySpectralExplicit(mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt)``
+    (python/src/fenicsxfus/_lossy.py:21-23; C++ ``LossySpectral3D``, Lossy.hpp:56-62).  Absorbing
+    term on every listed boundary facet, ``delta0`` = diffusivity of sound (DG0)."""
+
+    _kind = _abi.FUS_LOSSY
+
+    def __init__(self, mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order=4, dt=None, V=None,
+                 ctx: Context | None = None):
+        self._create(mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt, V, ctx)
+
+
+def compute_diffusivity_of_sound(w0: float, c0: float, alpha: float) -> float:
+    """delta = 2 alpha c0^3 / w0^2 (Lossy.hpp:376-381; python/src/fenicsxfus/utils.py)."""
+    return 2 * alpha * c0**3 / w0**2
 
 
 def group_finish_setup(models):

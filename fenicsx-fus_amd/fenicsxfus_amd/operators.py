@@ -35,8 +35,9 @@ class SpectralOperatorData:
     once).  ``V`` needs ``.mesh.geometry.x/.dofmap``, ``.tensor_dofmap`` (or ``.dofmap.list``
     already in tensor order), ``.nodes1d`` and ``.P``."""
 
-    def __init__(self, V, ctx: Context | None = None):
+    def __init__(self, V, ctx: Context | None = None, fields: int = 1):
         self.ctx = ctx or default_context()
+        self.fields = fields
         mesh = V.mesh
         self.V = V
         self.P = int(V.P)
@@ -50,10 +51,14 @@ class SpectralOperatorData:
         self.h = C.c_void_p()
         tdim = mesh.topology.dim
         order = 1 if gdm.shape[1] == (1 << tdim) else 2
-        check(lib().fus_op_create(self.ctx.h, C.c_int(tdim), C.c_int(self.P),
-                                  C.c_int(_abi.dtype_code(self.dtype)), C.c_int64(self.ncells),
-                                  C.c_int64(self.ndofs), ptr(tdm), ptr(nodes), ptr(xg),
-                                  C.c_int64(xg.shape[0]), ptr(gdm), C.c_int(order), C.byref(self.h)))
+        self.ctx.set_option("fields", fields)   # LDS sizing: 2 operator inputs for the lossy model
+        try:
+            check(lib().fus_op_create(self.ctx.h, C.c_int(tdim), C.c_int(self.P),
+                                      C.c_int(_abi.dtype_code(self.dtype)), C.c_int64(self.ncells),
+                                      C.c_int64(self.ndofs), ptr(tdm), ptr(nodes), ptr(xg),
+                                      C.c_int64(xg.shape[0]), ptr(gdm), C.c_int(order), C.byref(self.h)))
+        finally:
+            self.ctx.set_option("fields", 1)
         neigh = getattr(V, "neighbours", [])
         if neigh:
             ranks = np.array([r for r, _ in neigh], dtype=np.int32)

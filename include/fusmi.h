@@ -49,7 +49,8 @@ int fus_init(int device, fus_ctx** ctx);
 int fus_finalize(fus_ctx* ctx);
 int fus_synchronize(fus_ctx* ctx);
 /* Tunables, set before fus_op_create: "block_elems" (elements per LDS block, default 32),
- * "waves" (waves per workgroup, default 4), "deterministic" (1: elements accumulate in
+ * "waves" (waves per workgroup, default 4), "fields" (1 | 2: operator inputs the block kernel
+ * stages per pass; 2 is required by FUS_LOSSY), "deterministic" (1: elements accumulate in
  * conflict-free rounds, results bitwise reproducible; 0 (default): LDS floating-point atomics, the
  * order of the <= 8 adds per DOF inside a block is free).  Unknown keys -> FUS_ERR_ARG. */
 int fus_set_option(fus_ctx* ctx, const char* key, int64_t value);
@@ -132,7 +133,12 @@ int fus_op_set_neighbours(fus_op* op, int nneigh, const int32_t* ranks, const in
  * (Linear.hpp:55-158): c0, rho0 are the DG0 arrays (T[ncells]); boundary facets as
  * (cell, local facet, tag) with tag 1 = source, 2 = absorbing (forms.py:38-39).  Builds the lumped
  * mass m (Linear.hpp:127-134) and the operator coefficient -1/rho (:154-155) on the device.
- * delta0/beta0 are reserved for FUS_LOSSY / FUS_WESTERVELT (must be NULL for FUS_LINEAR). */
+ * FUS_LOSSY replaces LossySpectral3D (Lossy.hpp:56-173): delta0 = diffusivity of sound per cell; the
+ * two operator actions of a stage, lin_op(u_n, -1/rho) and att_op(v_n, -delta/(rho c^2))
+ * (Lossy.hpp:231-232), run as ONE pass of the block kernel (both share G); absorbing term on every
+ * listed facet, dg source term and the delta/(rho c^3) boundary mass term as in
+ * BM7-SC1/forms.py:37-42; source scaling 2 W p0 w0/s0 as live in Lossy.hpp:216-220.  The operator
+ * data must have been created with option "fields" = 2.  beta0 is reserved for FUS_WESTERVELT. */
 int fus_model_create(fus_ctx* ctx, int kind, fus_op* op, const void* c0, const void* rho0,
                      const void* delta0, const void* beta0, int64_t nfacets,
                      const int32_t* facet_cells, const int32_t* facet_local,

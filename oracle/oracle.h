@@ -85,14 +85,21 @@ void orc_dphi(int N, const double* nodes, double* D);
                             const int32_t* tensor_dofmap, REAL* out);                              \
   /* Linear.hpp:161-314: init + rk4 with the reference's 9-pass stage structure.                   \
    * m = lumped mass (Linear.hpp:127-134), src/absb = diagonal facet weights                       \
-   * (tag 1: 1/rho, tag 2: 1/(rho c)).  u,v in/out (u_n, v_n).  Returns #steps.                    \
-   * nthreads<=1: scalar; >1: OpenMP over the vector passes and a coloured                         \
-   * element loop is NOT used -- the operator stays the serial cell loop. */                       \
+   * (tag 1: 1/rho, tag 2: 1/(rho c)).  u,v in/out (u_n, v_n).  Returns #steps.  Scalar, serial   \
+   * cell loop like the reference. */                       \
   int64_t orc_linear_rk4_##SUF(int tdim, int64_t ncells, int64_t ndofs, int N,                     \
                                const int32_t* tensor_dofmap, const REAL* G, const REAL* dphi,      \
                                const REAL* coeff, const REAL* m, const REAL* src,                  \
                                const REAL* absb, double freq, double p0, double s0, double t0,     \
-                               double tf, double dt, REAL* u, REAL* v);
+                               double tf, double dt, REAL* u, REAL* v);                            \
+  /* Lossy.hpp:176-342 (f1 :196-250): two stiffness actions per stage (u with -1/rho, v with       \
+   * -delta/(rho c^2)), heterogeneous source scaling, dg term; see oracle_impl.h. */               \
+  int64_t orc_lossy_rk4_##SUF(int tdim, int64_t ncells, int64_t ndofs, int N,                      \
+                              const int32_t* tensor_dofmap, const REAL* G, const REAL* dphi,       \
+                              const REAL* lin_coeff, const REAL* att_coeff, const REAL* m,         \
+                              const REAL* src, const REAL* absb, const REAL* src2, double freq,    \
+                              double p0, double s0, double t0, double tf, double dt, REAL* u,      \
+                              REAL* v);
 
 ORC_DECL(f64, double)
 ORC_DECL(f32, float)

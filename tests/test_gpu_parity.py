@@ -167,6 +167,38 @@ def test_linear_rk4_vs_oracle(orc, ctx, hetero, perturb):
     model.close()
 
 
+@pytest.mark.parametrize("hetero", [False, True])
+def test_lossy_rk4_vs_oracle(orc, ctx, hetero):
+    # LossySpectral3D (Lossy.hpp:56-342): two operator actions per stage fused into one pass
+    L = 0.012
+    P, n = 4, (6, 6, 6)
+    pr, c, rho, tags = _linear_setup(orc, ctx, n, P, [L, L, L], perturb=0.1, hetero=hetero)
+    f0, p0, s0 = 0.5e6, 60000.0, 1500.0
+    w0 = 2 * np.pi * f0
+    delta = np.full(pr.mesh.num_cells, fa.compute_diffusivity_of_sound(w0, 1500.0, 0.2))
+    if hetero:   # attenuating bone, BM7-SC1/main.cpp:43-46 (alpha = 400/20 ln 10 Np/m ... scaled)
+        delta[c > 2000.0] = fa.compute_diffusivity_of_sound(w0, 2800.0, 400.0 / 20.0 * np.log(10.0))
+    dt = 0.5 * (L / n[0]) / (c.max() * P**2)
+    nsteps = 20
+    m, src, absb, src2, lin, att = pr.lossy_model_vectors(c, rho, delta, tags)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    ns = orc.lossy_rk4(3, pr.N, pr.dm, pr.G, pr.D, lin, att, m, src, absb, src2, f0, p0, s0, 0.0,
+                       nsteps * dt * (1 - 1e-9), dt, u, v)
+    assert ns == nsteps
+    model = fa.LossySpectralExplicit(pr.mesh, tags, P, c, rho, delta, f0, p0, s0, 4, dt, V=pr.V, ctx=ctx)
+    assert relmax(model.mass_vector(), m) < 1e-14
+    model.init()
+    un, vn, _ = model.rk(0.0, nsteps * dt * (1 - 1e-9))
+    assert np.abs(u).max() > 0
+    assert relmax(un.x.array, u) < TOL_RK and relmax(vn.x.array, v) < TOL_RK
+    # attenuation does something: differs from the linear model beyond tolerance
+    lm = fa.LinearSpectralExplicit(pr.mesh, tags, P, c, rho, f0, p0, s0, 4, dt, V=pr.V, ctx=ctx)
+    lm.init()
+    ul, _, _ = lm.rk(0.0, nsteps * dt * (1 - 1e-9))
+    assert relmax(un.x.array, 2 * ul.x.array) > 1e-6
+    model.close(), lm.close()
+
+
 def test_plane_wave_vs_analytical_gpu(orc, ctx):
     # python/tests/test_linearspectral_1d.py:12-107 (degree 4, epw 4): L2 error < 1e-3
     f0, c0, rho0, L, degree, epw = 10.0, 1.0, 4.0, 1.0, 4, 4

@@ -144,3 +144,29 @@ def test_plane_wave_vs_analytical(orc, degree, epw):
     w = pr.M(np.ones(pr.ndofs))
     err = np.sqrt(w @ (u - ue) ** 2) / np.sqrt(w @ ue**2)
     assert err < 1e-3, err
+
+
+def test_lossy_oracle_reduces_to_linear(orc):
+    """delta = 0: Lossy.hpp's f1 is Linear.hpp's with the source doubled (heterogeneous scaling,
+    Lossy.hpp:216-220 vs Linear.hpp:192) and the absorbing term on every facet; with only
+    source/absorbing facets listed both oracles must agree up to that factor 2 (linearity)."""
+    pr = Problem(orc, (4, 3, 3), 3, hi=[0.02, 0.015, 0.015], perturb=0.1)
+    tags = tag_box_boundary(pr.mesh)
+    keep = tags.values == 2      # absorbing faces only -> 'every facet' == tag 2 ...
+    src_keep = tags.values == 1  # ... except the source face, which the lossy form also absorbs on
+    c0, rho0 = 1500.0, 1000.0
+    nc = pr.mesh.num_cells
+    m, src, absb, coeff = pr.linear_model_vectors(c0, rho0, tags)
+    ml, srcl, absl, src2, lin, att = pr.lossy_model_vectors(c0, rho0, 0.0, tags)
+    assert np.array_equal(ml, m) and np.array_equal(srcl, src) and not src2.any()
+    f0, p0 = 0.5e6, 6e4
+    dt = 0.5 * (0.02 / 4) / (c0 * 9)
+    u1, v1 = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    u2, v2 = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    # same absorbing vector in both (the lossy 'all facets' one)
+    orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absl, f0, p0, c0, 0.0, 10 * dt * (1 - 1e-9), dt, u1, v1)
+    orc.lossy_rk4(3, pr.N, pr.dm, pr.G, pr.D, lin, att, ml, srcl, absl, src2, f0, p0, c0, 0.0,
+                  10 * dt * (1 - 1e-9), dt, u2, v2)
+    assert np.abs(u1).max() > 0
+    assert np.abs(u2 - 2 * u1).max() < 1e-12 * np.abs(u2).max()
+    assert keep.any() and src_keep.any()

@@ -50,3 +50,18 @@ class Problem:
         src = self.facet_diag(tags, 1, 1.0 / rho0)
         absb = self.facet_diag(tags, 2, 1.0 / (rho0 * c0))
         return m, src, absb, (-1.0 / rho0).astype(self.dtype)
+
+    def lossy_model_vectors(self, c0, rho0, delta0, tags):
+        """m, src, absb, src2, lin_coeff, att_coeff of the Lossy model (Lossy.hpp:133-141,166-169;
+        BM7-SC1/forms.py:37-42): absorbing + delta mass term on every listed boundary facet."""
+        nc = self.mesh.num_cells
+        c0 = np.broadcast_to(np.asarray(c0, self.dtype), (nc,)).copy()
+        rho0 = np.broadcast_to(np.asarray(rho0, self.dtype), (nc,)).copy()
+        d0 = np.broadcast_to(np.asarray(delta0, self.dtype), (nc,)).copy()
+        allf = FacetTags(tags.cells, tags.local_facets, np.full(len(tags.values), 7))
+        m = self.M(np.ones(self.ndofs, self.dtype), 1.0 / (rho0 * c0 * c0))
+        m = m + self.facet_diag(allf, 7, d0 / (rho0 * c0**3))
+        src = self.facet_diag(tags, 1, 1.0 / rho0)
+        absb = self.facet_diag(allf, 7, 1.0 / (rho0 * c0))
+        src2 = self.facet_diag(tags, 1, d0 / (rho0 * c0 * c0))
+        return m, src, absb, src2, (-1.0 / rho0).astype(self.dtype), (-d0 / (rho0 * c0 * c0)).astype(self.dtype)

@@ -84,6 +84,8 @@ def main():
     ap.add_argument("--block-elems", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
     ap.add_argument("--deterministic", type=int, default=None, help="1: conflict-free rounds, 0: LDS atomics")
+    ap.add_argument("--geometry", choices=["auto", "stream"], default="stream",
+                    help="stream: per-point G from HBM (reference data path); auto: per-cell factors on affine meshes")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=60)
@@ -105,7 +107,7 @@ def main():
 
     import fenicsxfus_amd as fa
 
-    ctx = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves, deterministic=args.deterministic)
+    ctx = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves, deterministic=args.deterministic, geometry=args.geometry)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run
     if world > 1 or launched:
         import torch.distributed as dist
@@ -157,7 +159,9 @@ def main():
         # One launch of the dominant kernel does the stiffness action for every DOF and the fused
         # stage update for the block-interior DOFs it completes (the shared DOFs' update runs in
         # k_stage on the shared range).
-        b_stiff = rho_e * (s + 4 + 6 * s) + s
+        affine = model.data.is_affine()
+        # B_general streams 6 s of G per element-DOF; B_affine rebuilds G from per-cell numbers
+        b_stiff = rho_e * (s + 4 + (0 if affine else 6 * s)) + s
         b_general = 4 * (b_stiff + 12 * s)
         n_int = info["interior_dofs"]
         alg_launch = b_stiff * ndl + 12 * s * n_int
@@ -171,7 +175,7 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01c_pmc_traffic.json")
         if (os.path.exists(pmc) and n == 64 and P == 4 and args.block_elems is None and args.waves is None
-                and not args.deterministic):
+                and not args.deterministic and not affine):
             traffic = json.load(open(pmc))["k_block_op_fused"]["hbm_bytes_per_launch"]
         out = {
             "metric": "DOF-updates/sec (RK4 step) at p=4 hex fp64",
@@ -188,7 +192,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"3D homogeneous wave, {n}^3 hex p={P} fp64 per GPU, Linear RK4 "
                                    f"(BASELINE.json configs[1])", "ndofs_global": int(ndofs_global),
-                       "cells_per_gpu": int(nc), "geometry": "general (G streamed, 6 fp64 per point)",
+                       "cells_per_gpu": int(nc), "geometry": "affine (7 fp64 per cell, B_affine)" if affine else "general (G streamed, 6 fp64 per point, B_general)",
                        "partition": f"x-slabs x{world}", "blocks": info["nblocks"],
                        "lds_bytes_per_block": info["lds_bytes"], "dt": dt},
             "roofline": {"bound": "hbm", "kernel": "k_block_op<double,4,stiffness,+fused RK4 stage>", "achieved": achieved,

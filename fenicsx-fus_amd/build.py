@@ -14,7 +14,16 @@ DEPS = SRC + [os.path.join(HERE, "csrc", f) for f in ("kernels.hpp", "layout.hpp
 OUT = os.path.join(HERE, "fenicsxfus_amd", "libfusmi.so")
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
+    """dev=True: P=4/fp64-only iteration build into abl/libfusmi_dev.so (use with FUSMI_LIB)."""
+    if dev:
+        out = os.path.join(HERE, "..", "abl", "libfusmi_dev.so")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+                               "-Wno-unused-value", "-munsafe-fp-atomics", "-DFUS_DEV_BUILD", *SRC, "-o", out,
+                               "-ldl", "-Wl,-rpath,/opt/rocm/lib"])
+        return out
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -27,4 +36,4 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv))

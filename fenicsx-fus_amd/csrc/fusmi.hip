@@ -125,6 +125,7 @@ struct fus_ctx
   hipStream_t stream = nullptr;
   int deterministic = 0;  // 1: conflict-free rounds (bitwise reproducible); 0: LDS atomics
   int fields = 1;         // operator inputs per block pass the ops are sized for (2: Lossy)
+  int geometry = 0;       // 0: auto (per-cell factors when every cell is affine), 1: always stream G
   int block_elems = 32, waves = 4;  // measured best on MI355X at p=4 fp64 (profiles/r01_block_sweep.txt)
   bool prof = false;
   std::map<std::string, Prof> profs;
@@ -163,6 +164,10 @@ struct fus_op
   size_t lds_bytes = 0;
   int deterministic = 0;
   int nfields = 1;
+  bool affine = false;     // GEOM_AFFINE path in use (d_Gc), streamed G/detJ built only on demand
+  void* d_Gc = nullptr;
+  void *d_xg = nullptr, *d_pts = nullptr, *d_wts = nullptr;
+  int32_t* d_xdm = nullptr;
   // neighbours (multi-GPU)
   std::vector<Neigh> neigh;
   int32_t* d_uidx = nullptr;  // unique interface dofs (internal)
@@ -251,7 +256,7 @@ struct ProfScope
 // -------------------------------------------------------------------------------------------------
 // typed implementation
 // -------------------------------------------------------------------------------------------------
-template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF>
+template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM>
 static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec,
                              const StageArgs<T>& S)
 {
@@ -262,11 +267,11 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
   static bool attr_set = false;  // per instantiation
   if (!attr_set)
   {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC, STAGE, NF>), dim3(op->L.nblocks),
+  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM>), dim3(op->L.nblocks),
                      dim3(64 * op->L.waves), op->lds_bytes, op->ctx->stream, op->A, Dk,
                      static_cast<const T*>(op->d_Dg), geo, coef, x, bvec,
                      static_cast<T*>(op->d_partial), S);
@@ -280,8 +285,17 @@ static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, 
 {
   if (NF > op->nfields)
     return fail(FUS_ERR_STATE, "operator data was not created for two-field models (option fields=2)");
-  return op->deterministic ? launch_block_op_v<T, P, OP, 0, STAGE, NF>(op, geo, coef, x, bvec, S)
-                           : launch_block_op_v<T, P, OP, 1, STAGE, NF>(op, geo, coef, x, bvec, S);
+  // geometry operand: per-cell factors (affine meshes) or the streamed per-point arrays
+  if (op->affine)
+  {
+    const T* gc = static_cast<const T*>(op->d_Gc);
+    return op->deterministic
+               ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_AFFINE>(op, gc, coef, x, bvec, S)
+               : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_AFFINE>(op, gc, coef, x, bvec, S);
+  }
+  return op->deterministic
+             ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_STREAM>(op, geo, coef, x, bvec, S)
+             : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_STREAM>(op, geo, coef, x, bvec, S);
 }
 
 template <typename T>
@@ -418,6 +432,25 @@ static int halo_exchange_local(fus_op** ops, int n)
   return FUS_OK;
 }
 
+// Per-point geometry factors in the streaming layouts (precompute.hpp:101-213, 33-94), computed on
+// the device.  Built at setup for non-affine meshes, on demand (fus_op_get_geometry) otherwise.
+template <typename T, int P>
+static int ensure_stream_geometry(fus_op* op)
+{
+  constexpr int N = P + 1, Nd = N * N * N;
+  if (op->d_G)
+    return FUS_OK;
+  hipStream_t st = op->ctx->stream;
+  FUSCHK(dalloc_bytes(op->allocs, &op->d_G, (size_t)op->ncells * 6 * Nd * sizeof(T), false, st));
+  FUSCHK(dalloc_bytes(op->allocs, &op->d_detJ, (size_t)op->ncells * Nd * sizeof(T), false, st));
+  hipLaunchKernelGGL((k_geometry<T, N>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st, op->ncells,
+                     op->d_cell_perm, static_cast<const T*>(op->d_xg), op->d_xdm,
+                     static_cast<const double*>(op->d_pts), static_cast<const double*>(op->d_wts),
+                     static_cast<T*>(op->d_G), static_cast<T*>(op->d_detJ));
+  HIPCHK(hipGetLastError());
+  return FUS_OK;
+}
+
 template <typename T, int P>
 static int op_setup_device(fus_op* op)
 {
@@ -462,40 +495,55 @@ static int op_setup_device(fus_op* op)
   if (op->lds_bytes > 160 * 1024)
     return fail(FUS_ERR_LIMIT, "block does not fit 160 KB of LDS; lower block_elems");
 
-  std::vector<T> Dg(N * N);
+  // derivative table followed by the 1-D weights (the affine path rebuilds w_q from them)
+  std::vector<T> Dg(N * N + N);
   for (int i = 0; i < N * N; ++i)
     Dg[i] = (T)op->D[i];
+  for (int i = 0; i < N; ++i)
+    Dg[N * N + i] = (T)op->wts[i];
   T* d_Dg;
   FUSCHK(upload(pool, &d_Dg, Dg, st));
   op->d_Dg = d_Dg;
 
-  // geometry on the device, straight into the streaming layouts
+  // mesh geometry stays on the device for the (possibly deferred) per-point factors
   T* d_xg;
-  int32_t* d_xdm;
-  double *d_pts, *d_wts;
-  std::vector<void*> tmp;
-  FUSCHK(dalloc(tmp, &d_xg, (size_t)op->nnodes * 3));
+  FUSCHK(dalloc(pool, &d_xg, (size_t)op->nnodes * 3));
   HIPCHK(hipMemcpyAsync(d_xg, op->h_geom_x.data(), (size_t)op->nnodes * 3 * sizeof(T),
                         hipMemcpyHostToDevice, st));
-  FUSCHK(upload(tmp, &d_xdm, op->h_geom_dm, st));
-  FUSCHK(upload(tmp, &d_pts, op->nodes, st));
-  FUSCHK(upload(tmp, &d_wts, op->wts, st));
-  FUSCHK(dalloc_bytes(pool, &op->d_G, (size_t)op->ncells * 6 * Nd * sizeof(T), false, st));
-  FUSCHK(dalloc_bytes(pool, &op->d_detJ, (size_t)op->ncells * Nd * sizeof(T), false, st));
-  hipLaunchKernelGGL((k_geometry<T, N>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st, op->ncells,
-                     op->d_cell_perm, d_xg, d_xdm, d_pts, d_wts, static_cast<T*>(op->d_G),
-                     static_cast<T*>(op->d_detJ));
-  HIPCHK(hipGetLastError());
+  double *d_pts, *d_wts;
+  FUSCHK(upload(pool, &op->d_xdm, op->h_geom_dm, st));
+  FUSCHK(upload(pool, &d_pts, op->nodes, st));
+  FUSCHK(upload(pool, &d_wts, op->wts, st));
+  op->d_xg = d_xg, op->d_pts = d_pts, op->d_wts = d_wts;
+  op->d_G = op->d_detJ = nullptr;
 
-  // + one slot per shared dof for the boundary pseudo pairs of the models
+  // per-cell factors + affinity test (every cell a parallelepiped?)
+  T* d_Gc;
+  unsigned int* d_err;
+  FUSCHK(dalloc(pool, &d_Gc, (size_t)op->ncells * 7));
+  FUSCHK(dalloc(pool, &d_err, 1));
+  HIPCHK(hipMemsetAsync(d_err, 0, sizeof(unsigned int), st));
+  hipLaunchKernelGGL((k_geometry_affine<T>), dim3(nblk(op->ncells)), dim3(256), 0, st, op->ncells,
+                     op->d_cell_perm, d_xg, op->d_xdm, d_Gc, d_err);
+  HIPCHK(hipGetLastError());
+  unsigned int err_bits = 0;
+  HIPCHK(hipMemcpyAsync(&err_bits, d_err, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  float rel_err;
+  memcpy(&rel_err, &err_bits, sizeof(float));
+  op->d_Gc = d_Gc;
+  op->affine = c->geometry == 0 && rel_err <= (sizeof(T) == 8 ? 1e-12f : 1e-6f);
+  if (op->affine)
+    op->lds_bytes = L.lds_bytes(sizeof(T), op->nfields, true);
+  else
+    FUSCHK((ensure_stream_geometry<T, P>(op)));
+
   FUSCHK(dalloc_bytes(pool, &op->d_partial, (size_t)(L.npairs + L.n_shared) * sizeof(T), true, st));
   FUSCHK(dalloc_bytes(pool, &op->d_tmp_x, (size_t)L.n_internal * sizeof(T), true, st));
   FUSCHK(dalloc_bytes(pool, &op->d_tmp_b, (size_t)L.n_internal * sizeof(T), true, st));
   FUSCHK(dalloc_bytes(pool, &op->d_tmp_c, (size_t)op->ndofs * sizeof(T), true, st));
   FUSCHK(dalloc_bytes(pool, &op->d_tmp_coef, (size_t)op->ncells * sizeof(T) * 2, true, st));
   HIPCHK(hipStreamSynchronize(st));
-  for (void* q : tmp)
-    (void)hipFree(q);
   return FUS_OK;
 }
 
@@ -545,6 +593,7 @@ static int op_get_geometry(fus_op* op, void* G, void* detJ)
 {
   constexpr int N = P + 1, Nd = N * N * N;
   hipStream_t st = op->ctx->stream;
+  FUSCHK((ensure_stream_geometry<T, P>(op)));
   std::vector<void*> tmp;
   T *dG = nullptr, *dd = nullptr;
   if (G)
@@ -1019,6 +1068,22 @@ static int model_getset(fus_model* m, int which, void* host_or_dev, int space, b
 // -------------------------------------------------------------------------------------------------
 // dispatch over (dtype, P)
 // -------------------------------------------------------------------------------------------------
+#ifdef FUS_DEV_BUILD  // developer iteration build: P = 4, fp64 only (never shipped; build.py --dev)
+#define FUS_DISPATCH_P(T, P_, CALL)                                                                \
+  switch (P_)                                                                                      \
+  {                                                                                                \
+  case 4: { constexpr int PP = 4; return CALL; }                                                   \
+  default: return fail(FUS_ERR_ARG, "dev build: P = 4 only");                                      \
+  }
+#define FUS_DISPATCH(dtype_, P_, CALL)                                                             \
+  do                                                                                               \
+  {                                                                                                \
+    if ((dtype_) != FUS_F64)                                                                       \
+      return fail(FUS_ERR_ARG, "dev build: fp64 only");                                            \
+    typedef double TT;                                                                             \
+    FUS_DISPATCH_P(TT, P_, CALL)                                                                   \
+  } while (0)
+#else
 #define FUS_DISPATCH_P(T, P_, CALL)                                                                \
   switch (P_)                                                                                      \
   {                                                                                                \
@@ -1044,6 +1109,7 @@ static int model_getset(fus_model* m, int which, void* host_or_dev, int space, b
       FUS_DISPATCH_P(TT, P_, CALL)                                                                 \
     }                                                                                              \
   } while (0)
+#endif
 
 static int d_op_setup(fus_op* op) { FUS_DISPATCH(op->dtype, op->P, (op_setup_device<TT, PP>(op))); }
 static int d_op_apply(fus_op* op, int kind, const void* x, const void* cf, void* y, int space)
@@ -1197,12 +1263,18 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
   }
   else if (!strcmp(key, "waves"))
   {
-    if (value != 1 && value != 2 && value != 4)
-      return fail(FUS_ERR_ARG, "waves must be 1, 2 or 4");
+    if (value != 1 && value != 2 && value != 4 && value != 8)
+      return fail(FUS_ERR_ARG, "waves must be 1, 2, 4 or 8");
     c->waves = (int)value;
   }
   else if (!strcmp(key, "deterministic"))
     c->deterministic = value != 0;
+  else if (!strcmp(key, "geometry"))
+  {
+    if (value != 0 && value != 1)
+      return fail(FUS_ERR_ARG, "geometry must be 0 (auto) or 1 (stream)");
+    c->geometry = (int)value;
+  }
   else if (!strcmp(key, "fields"))
   {
     if (value != 1 && value != 2)
@@ -1380,6 +1452,8 @@ static void layout_info(const Layout& L, size_t ts, int64_t out[8])
   out[6] = (int64_t)L.lds_bytes(ts);
   out[7] = L.n_internal;
 }
+
+int fus_op_is_affine(fus_op* op) { return (op && op->affine) ? 1 : 0; }
 
 int fus_op_info(fus_op* op, int64_t out[8])
 {

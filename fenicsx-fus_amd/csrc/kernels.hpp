@@ -109,28 +109,39 @@ enum
   OP_MASS = 1
 };
 
+// Geometry source of the block operator
+//   GEOM_STREAM: per-point factors G / detJw streamed from HBM (any trilinear mesh; the reference's
+//                data path, precompute.hpp:101-213)
+//   GEOM_AFFINE: every cell is a parallelepiped (J constant per cell): 6 + 1 numbers per CELL,
+//                G(q) = Gc * w_q and detJw(q) = detc * w_q rebuilt in registers
+enum
+{
+  GEOM_STREAM = 0,
+  GEOM_AFFINE = 1
+};
+
 // ---------------------------------------------------------------------------------------------
 // Per-element inputs fetched from HBM one round ahead of their use (software pipeline):
 // local dof indices, geometry factors (stiffness) or detJw (mass), cell coefficient.
-template <typename T, int N, int OP>
+template <typename T, int N, int OP, int GEOM>
 struct ElemIn
 {
   typedef typename GLoad<T, N>::type GV;
   static constexpr int NV = GLoad<T, N>::NV;
   int er;
-  GV g[OP == OP_STIFFNESS ? NV : 1];
-  T dj[OP == OP_MASS ? N : 1];
+  GV g[(OP == OP_STIFFNESS && GEOM == GEOM_STREAM) ? NV : 1];
+  T dj[(OP == OP_MASS && GEOM == GEOM_STREAM) ? N : 1];
 };
 
-template <typename T, int N, int OP>
-__device__ __forceinline__ void elem_fetch(ElemIn<T, N, OP>& in, int er, const T* __restrict__ geo,
-                                           int elem_off, int p)
+template <typename T, int N, int OP, int GEOM>
+__device__ __forceinline__ void elem_fetch(ElemIn<T, N, OP, GEOM>& in, int er,
+                                           const T* __restrict__ geo, int elem_off, int p)
 {
   constexpr int N2 = N * N, Nd = N * N * N;
   constexpr int VW = GLoad<T, N>::VW, NV = GLoad<T, N>::NV;
   typedef typename GLoad<T, N>::type GV;
   in.er = er;
-  if (er >= 0)
+  if (GEOM == GEOM_STREAM && er >= 0)
   {
     const int64_t e = elem_off + er;
     if (OP == OP_STIFFNESS)
@@ -156,14 +167,15 @@ __device__ __forceinline__ void elem_fetch(ElemIn<T, N, OP>& in, int er, const T
 // One element's operator action, accumulated into the block's LDS vector y_l.
 // ATOMIC: the accumulation is an LDS floating-point atomic (ds_add_f64 / ds_add_f32), so waves need
 // not proceed in conflict-free rounds; otherwise a plain read-modify-write (deterministic).
-template <typename T, int N, int OP, int ATOMIC, int NF>
-__device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP>& in, const DTab<T, N>& Dk,
+template <typename T, int N, int OP, int ATOMIC, int NF, int GEOM>
+__device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, const DTab<T, N>& Dk,
                                              const T (&Drb)[N], const T (&Drc)[N], const T (&Dcb)[N],
                                              const T (&Dcc)[N], const T* __restrict__ x_l,
                                              T* __restrict__ y_l, T* __restrict__ sA,
                                              T* __restrict__ sB, const uint16_t* __restrict__ ldm_l,
                                              const T* __restrict__ cf_l, const T* __restrict__ x2_l,
-                                             const T* __restrict__ cf2_l, int p, int b, int c)
+                                             const T* __restrict__ cf2_l, const T* __restrict__ gc_l,
+                                             const T (&w3)[N], int p, int b, int c)
 {
   constexpr int N2 = N * N, Nd = N * N * N;
   constexpr int VW = GLoad<T, N>::VW;
@@ -178,7 +190,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP>& in, const D
   const T cf = (NF == 2) ? T(1) : cf_l[in.er];
   T Y[N];
 #if defined(FUS_ABLATE) && FUS_ABLATE == 1  // timing experiment: loads only, no contractions
-  if (OP == OP_STIFFNESS)
+  if (OP == OP_STIFFNESS && GEOM == GEOM_STREAM)
   {
 #pragma unroll
     for (int a = 0; a < N; ++a)
@@ -248,7 +260,10 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP>& in, const D
       for (int gi = 0; gi < 6; ++gi)
       {
         const int v = gi * N + a;
-        G6[gi] = in.g[v / VW][v % VW];
+        if (GEOM == GEOM_STREAM)
+          G6[gi] = in.g[v / VW][v % VW];
+        else
+          G6[gi] = gc_l[in.er * 7 + gi] * w3[a];   // affine cell: G(q) = Gc w_q
       }
       const T w0 = F0[a], w1 = F1[a], w2 = F2[a];
       F0[a] = cf * (G6[0] * w0 + G6[1] * w1 + G6[2] * w2);
@@ -285,7 +300,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP>& in, const D
     // mass::transform (spectral_op.hpp:19-26)
 #pragma unroll
     for (int a = 0; a < N; ++a)
-      Y[a] = cf * x_l[li[a]] * in.dj[a];
+      Y[a] = cf * x_l[li[a]] * (GEOM == GEOM_STREAM ? in.dj[a] : gc_l[in.er * 7 + 6] * w3[a]);
   }
   // scatter-add into the block accumulator (spectral_op.hpp:240-241); elements of one round
   // share no dof and rounds are ordered -> deterministic
@@ -308,8 +323,8 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP>& in, const D
 // :203-221): for the block's interior dofs the sum in LDS is complete, so b never goes to HBM --
 // boundary terms are added in LDS, kv = b * minv, and u_, v_, un', vn' (or the new u0, v0 at stage 3)
 // are written straight from here.  Shared dofs still leave as partial sums.
-template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF>
-__global__ void __launch_bounds__(256)
+template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM>
+__global__ void __launch_bounds__(512)
 k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
            const T* __restrict__ geo, const T* __restrict__ coef, const T* __restrict__ x,
            T* __restrict__ bvec, T* __restrict__ partial, const StageArgs<T> S)
@@ -325,7 +340,9 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   T* D_l = scratch + (size_t)A.waves * EPW * 2 * Nd;      // derivative table
   T* cf_l = D_l + N2;                                       // per-element coefficient(s)
   T* cf2_l = cf_l + A.lds_nelem;
-  uint16_t* ldm_l = reinterpret_cast<uint16_t*>(cf2_l + (NF == 2 ? A.lds_nelem : 0));  // 16-B aligned
+  T* gc_l = cf2_l + (NF == 2 ? A.lds_nelem : 0);            // affine cells: 6 G + 1 detJ per element
+  T* w_l = gc_l + (GEOM == GEOM_AFFINE ? 7 * A.lds_nelem : 0);  // 1-D weights (8 slots)
+  uint16_t* ldm_l = reinterpret_cast<uint16_t*>(w_l + (GEOM == GEOM_AFFINE ? 8 : 0));  // 16-B aligned
   int16_t* rt_l = reinterpret_cast<int16_t*>(ldm_l + (size_t)A.lds_nelem * Nd);
 
   const int blk = blockIdx.x;
@@ -354,12 +371,12 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   };
 
   // first trip's geometry is requested before the block's dof values are staged
-  ElemIn<T, N, OP> inA, inB;
+  ElemIn<T, N, OP, GEOM> inA, inB;
   {
     int e0 = -1;
     if (active && ntrips > 0)
       e0 = ATOMIC ? (myslot < sh.nelem ? myslot : -1) : (int)A.rounds[sh.rounds_off + myslot];
-    elem_fetch<T, N, OP>(inA, e0, geo, elem_off, p);
+    elem_fetch<T, N, OP, GEOM>(inA, e0, geo, elem_off, p);
   }
 
   // ---- prologue: stage the block's dof values in LDS, clear the accumulator; all loads of a
@@ -444,6 +461,15 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     }
     if (tid < N2)
       D_l[tid] = Dg[tid];
+    if (GEOM == GEOM_AFFINE)
+    {
+      // per-cell geometry (geo = [elem][7]: Gxx,Gxy,Gxz,Gyy,Gyz,Gzz,|detJ|) and the 1-D weights
+      // (Dg carries them after the N*N table)
+      for (int k = tid; k < sh.nelem * 7; k += nthr)
+        gc_l[k] = geo[(int64_t)elem_off * 7 + k];
+      if (tid < N)
+        w_l[tid] = Dg[N2 + tid];
+    }
   }
 
   T* sA = scratch + (size_t)(wave * EPW + (active ? s : 0)) * 2 * Nd;
@@ -460,19 +486,23 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     Dcb[j] = (OP == OP_STIFFNESS) ? D_l[j * N + b] : T(0);
     Dcc[j] = (OP == OP_STIFFNESS) ? D_l[j * N + c] : T(0);
   }
+  T w3[N];  // w_q = w_a w_b w_c of this lane's points (affine geometry only)
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    w3[a] = (GEOM == GEOM_AFFINE) ? w_l[a] * w_l[b] * w_l[c] : T(0);
 
   // ---- trips, two per iteration: while one register set is consumed the other is in flight ----
   for (int r = 0; r < ntrips; r += 2)
   {
     const bool has1 = r + 1 < ntrips;
-    elem_fetch<T, N, OP>(inB, elem_of(r + 1), geo, elem_off, p);
-    elem_compute<T, N, OP, ATOMIC, NF>(inA, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, x2_l, cf2_l, p, b, c);
+    elem_fetch<T, N, OP, GEOM>(inB, elem_of(r + 1), geo, elem_off, p);
+    elem_compute<T, N, OP, ATOMIC, NF, GEOM>(inA, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, x2_l, cf2_l, gc_l, w3, p, b, c);
     if (!ATOMIC && A.waves > 1)
       __syncthreads();
-    elem_fetch<T, N, OP>(inA, elem_of(r + 2), geo, elem_off, p);
+    elem_fetch<T, N, OP, GEOM>(inA, elem_of(r + 2), geo, elem_off, p);
     if (has1)
     {
-      elem_compute<T, N, OP, ATOMIC, NF>(inB, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, x2_l, cf2_l, p, b, c);
+      elem_compute<T, N, OP, ATOMIC, NF, GEOM>(inB, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, x2_l, cf2_l, gc_l, w3, p, b, c);
       if (!ATOMIC && A.waves > 1)
         __syncthreads();
     }
@@ -726,6 +756,48 @@ __global__ void k_geometry(int64_t ncells, const int32_t* __restrict__ cell_perm
   detJ[e * Nd + q] = dw;
   for (int gi = 0; gi < 6; ++gi)
     G[e * (6 * Nd) + g_index<T, N>(gi * N + a, p)] = G6[gi];
+}
+
+// Affine cells: Gc[e][0..5] = K K^T |det J| (no quadrature weight), Gc[e][6] = |det J| with the
+// constant Jacobian J = [x1-x0, x2-x0, x4-x0] (same formulas as geometric_factor3 with w = 1).
+// affine_err_bits receives the largest deviation of the other vertices from the parallelepiped,
+// relative to the cell size: the host falls back to GEOM_STREAM when it is not ~0.
+template <typename T>
+__global__ void k_geometry_affine(int64_t ncells, const int32_t* __restrict__ cell_perm,
+                                  const T* __restrict__ xg, const int32_t* __restrict__ xdofmap,
+                                  T* __restrict__ Gc, unsigned int* __restrict__ affine_err_bits)
+{
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ncells)
+    return;
+  const int64_t cell = cell_perm[e];
+  T cd[8][3];
+  for (int v = 0; v < 8; ++v)
+    for (int j = 0; j < 3; ++j)
+      cd[v][j] = xg[3 * (int64_t)xdofmap[cell * 8 + v] + j];
+  T J[3][3], G6[6];
+  T h2 = T(0);
+  for (int i = 0; i < 3; ++i)
+  {
+    J[i][0] = cd[1][i] - cd[0][i];
+    J[i][1] = cd[2][i] - cd[0][i];
+    J[i][2] = cd[4][i] - cd[0][i];
+    h2 += J[i][0] * J[i][0] + J[i][1] * J[i][1] + J[i][2] * J[i][2];
+  }
+  T err2 = T(0);
+  for (int v = 0; v < 8; ++v)
+    for (int i = 0; i < 3; ++i)
+    {
+      const T pred = cd[0][i] + (T)(v & 1) * J[i][0] + (T)((v >> 1) & 1) * J[i][1] + (T)(v >> 2) * J[i][2];
+      const T d = cd[v][i] - pred;
+      err2 = (d * d > err2) ? d * d : err2;
+    }
+  const T dw = geometric_factor3<T>(J, T(1), G6);
+  for (int gi = 0; gi < 6; ++gi)
+    Gc[e * 7 + gi] = G6[gi];
+  Gc[e * 7 + 6] = dw;
+  const float rel = (float)sqrt((double)(err2 / h2));
+  atomicMax(affine_err_bits, __float_as_uint(rel));  // non-negative floats order like their bits
 }
 
 // internal streaming layout -> reference layout G[cell][point][6], detJ[cell][point]

@@ -19,7 +19,7 @@ FUS_U, FUS_V = 0, 1
 SYMBOLS = [
     "fus_last_error", "fus_version", "fus_init", "fus_finalize", "fus_synchronize", "fus_set_option",
     "fus_comm_unique_id", "fus_comm_init", "fus_comm_selftest", "fus_op_create", "fus_op_destroy", "fus_stiffness_apply",
-    "fus_mass_apply", "fus_op_get_geometry", "fus_op_get_tables", "fus_op_info", "fus_facet_diag",
+    "fus_mass_apply", "fus_op_get_geometry", "fus_op_get_tables", "fus_op_info", "fus_op_is_affine", "fus_facet_diag",
     "fus_op_set_neighbours", "fus_model_create", "fus_model_destroy", "fus_model_init", "fus_model_rk4",
     "fus_model_rk4_steps", "fus_model_get", "fus_model_set", "fus_model_get_mass", "fus_model_ndofs",
     "fus_profile_enable", "fus_profile_get", "fus_layout_check", "fus_comm_init_local",
@@ -70,7 +70,7 @@ class Context:
     """One per GPU (fus_init)."""
 
     def __init__(self, device: int = 0, block_elems: int | None = None, waves: int | None = None,
-                 deterministic: bool | None = None):
+                 deterministic: bool | None = None, geometry: str | None = None):
         self.h = C.c_void_p()
         check(lib().fus_init(C.c_int(device), C.byref(self.h)))
         if block_elems is not None:
@@ -79,6 +79,8 @@ class Context:
             self.set_option("waves", waves)
         if deterministic is not None:
             self.set_option("deterministic", int(deterministic))
+        if geometry is not None:   # "auto": per-cell factors on affine meshes; "stream": always stream G
+            self.set_option("geometry", {"auto": 0, "stream": 1}[geometry])
         self.rank, self.nranks = 0, 1
 
     def set_option(self, key: str, value: int):

@@ -101,6 +101,9 @@ class SpectralOperatorData:
                 "internal_len"]
         return dict(zip(keys, list(out)))
 
+    def is_affine(self) -> bool:
+        return bool(lib().fus_op_is_affine(self.h))
+
     def facet_diag(self, cells, local_facets, cellcoef):
         cells = np.ascontiguousarray(cells, dtype=np.int32)
         lf = np.ascontiguousarray(local_facets, dtype=np.int32)

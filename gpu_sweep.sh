@@ -5,5 +5,5 @@ for a in "$@"; do
   tail -1 gpurun_out/bench_sweep.log | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())
-print('$a: value %.4e ms/step %.3f stiff_ms %.4f kfrac %.3f stepfrac %.3f lds %d blocks %d'%(d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['step_roofline']['frac_of_8TBps'], d['config']['lds_bytes_per_block'], d['config']['blocks']))" || tail -5 gpurun_out/bench_sweep.log
+print('$a: geom %s value %.4e ms/step %.3f stiff_ms %.4f kfrac %.3f stepfrac %.3f lds %d blocks %d'%(d['config']['geometry'][:7], d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['step_roofline']['frac_of_8TBps'], d['config']['lds_bytes_per_block'], d['config']['blocks']))" || tail -5 gpurun_out/bench_sweep.log
 done

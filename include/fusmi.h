@@ -49,7 +49,8 @@ int fus_init(int device, fus_ctx** ctx);
 int fus_finalize(fus_ctx* ctx);
 int fus_synchronize(fus_ctx* ctx);
 /* Tunables, set before fus_op_create: "block_elems" (elements per LDS block, default 32),
- * "waves" (waves per workgroup, default 4), "fields" (1 | 2: operator inputs the block kernel
+ * "waves" (waves per workgroup, default 4), "geometry" (0 auto | 1 always stream the
+ * per-point factors), "fields" (1 | 2: operator inputs the block kernel
  * stages per pass; 2 is required by FUS_LOSSY), "deterministic" (1: elements accumulate in
  * conflict-free rounds, results bitwise reproducible; 0 (default): LDS floating-point atomics, the
  * order of the <= 8 adds per DOF inside a block is free).  Unknown keys -> FUS_ERR_ARG. */
@@ -110,6 +111,10 @@ int fus_op_get_tables(fus_op* op, double* weights, double* dphi);
  * pairs out[4]=max local dofs per block out[5]=unique block shapes out[6]=LDS bytes per block
  * out[7]=padded internal vector length. */
 int fus_op_info(fus_op* op, int64_t out[8]);
+/* 1 when every cell was found to be a parallelepiped and the operator rebuilds G = Gc w_q from 7
+ * numbers per cell instead of streaming 6 per point (option "geometry" = 0, the default); 0 when
+ * the per-point factors are streamed (general trilinear meshes, or option "geometry" = 1). */
+int fus_op_is_affine(fus_op* op);
 
 /* out[dof] += cellcoef[cell] * |J_facet| w_a w_b at the GLL nodes of each listed boundary facet,
  * facets given as (cell, local facet) pairs in DOLFINx numbering (hex: 0:z=0 1:y=0 2:x=0 3:x=1

@@ -84,6 +84,34 @@ def test_reference_operator_test_recipe(orc, ctx):
     d.close()
 
 
+@pytest.mark.parametrize("P", [2, 4, 7])
+def test_affine_geometry_path(orc, P):
+    """Affine meshes (every cell a parallelepiped) take the per-cell geometry path (7 numbers per cell,
+    G(q) = Gc w_q); it must agree with the streamed per-point path and with the oracle, and a
+    perturbed mesh must fall back to streaming."""
+    n = (5, 4, 3) if P <= 4 else (3, 2, 2)
+    pr = Problem(orc, n, P, hi=[1.5, 1.0, 0.8])
+    rng = np.random.default_rng(P)
+    x, coef = rng.standard_normal(pr.ndofs), rng.uniform(0.5, 2.0, pr.mesh.num_cells)
+    ca, cs = fa.Context(0, geometry="auto"), fa.Context(0, geometry="stream")
+    da, ds = fa.SpectralOperatorData(pr.V, ca), fa.SpectralOperatorData(pr.V, cs)
+    assert da.is_affine() and not ds.is_affine()
+    ref = pr.K(x, coef)
+    ya = da.stiffness(x, coef, np.zeros(pr.ndofs))
+    ys = ds.stiffness(x, coef, np.zeros(pr.ndofs))
+    assert relmax(ya, ref) < TOL_OP and relmax(ys, ref) < TOL_OP
+    assert relmax(da.mass(x, coef, np.zeros(pr.ndofs)), pr.M(x, coef)) < 1e-14
+    G, dJ = da.geometry()           # per-point factors built on demand
+    assert relmax(G, pr.G) < 1e-13 and relmax(dJ, pr.detJ) < 1e-13
+    pp = Problem(orc, n, P, hi=[1.5, 1.0, 0.8], perturb=0.1)
+    dp = fa.SpectralOperatorData(pp.V, ca)
+    assert not dp.is_affine()
+    assert relmax(dp.stiffness(x, coef, np.zeros(pr.ndofs)), pp.K(x, coef)) < TOL_OP
+    for d in (da, ds, dp):
+        d.close()
+    ca.close(), cs.close()
+
+
 def test_node_order_invariance_gpu(orc, ctx):
     P = 4
     order = np.r_[0, P, 1:P]          # endpoints first (Basix-like 1-D order, SURVEY A.7)

@@ -86,6 +86,8 @@ def main():
     ap.add_argument("--deterministic", type=int, default=None, help="1: conflict-free rounds, 0: LDS atomics")
     ap.add_argument("--geometry", choices=["auto", "stream"], default="stream",
                     help="stream: per-point G from HBM (reference data path); auto: per-cell factors on affine meshes")
+    ap.add_argument("--both-geometries", type=int, default=1,
+                    help="also time the other geometry path and report it under 'other_geometry'")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=60)
@@ -117,6 +119,8 @@ def main():
         ids = [fa.Context.unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(rank, world, ids[0])
+        ids2 = [fa.Context.unique_id() if rank == 0 else None]   # communicator of the secondary run
+        dist.broadcast_object_list(ids2, src=0)
 
     def barrier():
         if world > 1 or launched:
@@ -127,28 +131,48 @@ def main():
     P, n = args.P, args.cells
     mesh, V, tags, c0, rho0, freq, p0, dt = workload(n, P, rank, world)
     nc = mesh.num_cells
-    model = fa.LinearSpectralExplicit(mesh, tags, P, np.full(nc, c0), np.full(nc, rho0), freq, p0, c0, 4, dt, V=V,
-                                      ctx=ctx)
-    model.init()
     ndofs_global = V.dofmap.index_map.size_global
-    info = model.data.info()
 
-    model.rk4_steps(0.0, dt, args.warmup)
-    ctx.profile_enable(True)
-    barrier()
-    t0 = time.perf_counter()
-    model.rk4_steps(args.warmup * dt, dt, args.steps, sync=False)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1 or launched:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    prof = {k: ctx.profile_get(k) for k in ("stiffness", "shared", "boundary", "stage", "halo")}
-    ctx.profile_enable(False)
+    def run(context, steps, warmup, profile):
+        """Build the model on `context`, run warmup + timed steps; returns timings and model info."""
+        model = fa.LinearSpectralExplicit(mesh, tags, P, np.full(nc, c0), np.full(nc, rho0), freq, p0, c0, 4, dt,
+                                          V=V, ctx=context)
+        model.init()
+        info = model.data.info()
+        affine = model.data.is_affine()
+        model.rk4_steps(0.0, dt, warmup)
+        if profile:
+            context.profile_enable(True)
+        barrier()
+        t0 = time.perf_counter()
+        model.rk4_steps(warmup * dt, dt, steps, sync=False)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if world > 1 or launched:
+            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            elapsed = float(tt.item())
+        prof = {}
+        if profile:
+            prof = {k: context.profile_get(k) for k in ("stiffness", "shared", "boundary", "stage", "halo")}
+            context.profile_enable(False)
+        u = model.u_sol().x.array
+        finite = bool(np.isfinite(u).all()) and float(np.abs(u).max()) > 0.0
+        model.close()
+        return elapsed, prof, info, affine, finite
 
-    u = model.u_sol().x.array
-    finite = bool(np.isfinite(u).all()) and float(np.abs(u).max()) > 0.0
+    elapsed, prof, info, affine, finite = run(ctx, args.steps, args.warmup, True)
+    # secondary measurement: the same workload through the other geometry path (the box mesh is
+    # affine: "auto" rebuilds G from 7 numbers per cell instead of streaming 6 per point)
+    other = None
+    if args.both_geometries:
+        ctx2 = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves,
+                          deterministic=args.deterministic, geometry="auto" if args.geometry == "stream" else "stream")
+        if world > 1:
+            ctx2.comm_init(rank, world, ids2[0])
+        e2, _, _, aff2, fin2 = run(ctx2, args.steps, args.warmup, False)
+        other = (e2, aff2, fin2)
+        ctx2.close()
 
     if rank == 0:
         s = 8
@@ -159,7 +183,6 @@ def main():
         # One launch of the dominant kernel does the stiffness action for every DOF and the fused
         # stage update for the block-interior DOFs it completes (the shared DOFs' update runs in
         # k_stage on the shared range).
-        affine = model.data.is_affine()
         # B_general streams 6 s of G per element-DOF; B_affine rebuilds G from per-cell numbers
         b_stiff = rho_e * (s + 4 + (0 if affine else 6 * s)) + s
         b_general = 4 * (b_stiff + 12 * s)
@@ -206,10 +229,17 @@ def main():
             "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
             "finite_nonzero_solution": finite,
         }
+        if other is not None:
+            e2, aff2, fin2 = other
+            b2 = 4 * (rho_e * (s + 4 + (0 if aff2 else 6 * s)) + s + 12 * s)
+            v2 = ndofs_global * args.steps / e2
+            out["other_geometry"] = {"geometry": "affine (7 fp64 per cell, B_affine)" if aff2 else
+                                     "general (G streamed, B_general)", "value": v2, "unit": "DOF-updates/s",
+                                     "ms_per_step": 1e3 * e2 / args.steps, "algorithmic_bytes_per_dof_update": b2,
+                                     "frac_of_8TBps": b2 * v2 / world / 8e12, "finite_nonzero_solution": fin2}
         if not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(P, args.cpu_n, args.cpu_steps)
         print(json.dumps(out))
-    model.close()
     if world > 1 or launched:
         dist.barrier()
         dist.destroy_process_group()

@@ -184,6 +184,7 @@ struct fus_model
   void *u0 = nullptr, *v0 = nullptr, *u_ = nullptr, *v_ = nullptr, *un = nullptr, *vn = nullptr,
        *b = nullptr, *minv = nullptr, *m = nullptr, *coef = nullptr, *coef2 = nullptr;
   void* d_bsrc2 = nullptr;  // lossy: delta/(rho c^2) w_f on the source facets (dg term)
+  void* mn1 = nullptr;      // Westervelt: diag of M(-2 beta/(rho^2 c^4)), internal numbering
   // boundary dofs (diagonal source / absorbing weights), sorted by internal index:
   // [0, nb_int) are block-interior (applied in the fused epilogue through d_blk_bnd_off),
   // [nb_int, nb) are shared dofs (applied by k_boundary after the partial sums are reduced)
@@ -658,7 +659,8 @@ static void facet_diag_host(const fus_op* op, int64_t nfacets, const int32_t* fc
 
 template <typename T, int P>
 static int model_setup(fus_model* m, const void* c0_, const void* rho0_, const void* delta0_,
-                       int64_t nfacets, const int32_t* fc, const int32_t* fl, const int32_t* ft)
+                       const void* beta0_, int64_t nfacets, const int32_t* fc, const int32_t* fl,
+                       const int32_t* ft)
 {
   fus_op* op = m->op;
   fus_ctx* c = m->ctx;
@@ -668,7 +670,8 @@ static int model_setup(fus_model* m, const void* c0_, const void* rho0_, const v
   const T* c0 = static_cast<const T*>(c0_);
   const T* rho0 = static_cast<const T*>(rho0_);
   const T* delta0 = static_cast<const T*>(delta0_);
-  const bool lossy = m->kind == FUS_LOSSY;
+  const bool lossy = m->kind == FUS_LOSSY || m->kind == FUS_WESTERVELT;
+  const T* beta0 = static_cast<const T*>(beta0_);
   auto& pool = m->allocs;
   for (void** v : {&m->u0, &m->v0, &m->u_, &m->v_, &m->un, &m->vn, &m->b, &m->minv, &m->m})
     FUSCHK(dalloc_bytes(pool, v, n * sizeof(T), true, st));
@@ -695,6 +698,22 @@ static int model_setup(fus_model* m, const void* c0_, const void* rho0_, const v
   T* ones = static_cast<T*>(m->un);
   hipLaunchKernelGGL((k_fill<T>), dim3(1024), dim3(256), 0, st, n, ones, T(1));
   FUSCHK((apply_internal<T, P, OP_MASS>(op, d_mcoef, ones, static_cast<T*>(m->m))));
+  if (m->kind == FUS_WESTERVELT)
+  {
+    // diagonal of the nonlinear mass action: mn1 = M(-2 beta/(rho^2 c^4)) 1  (Westervelt.hpp:185,
+    // 249-254); nlin2 = -nlin1 (:186), so the RHS term is -mn1 .* v_n^2
+    std::vector<T> n1(op->ncells);
+    for (int64_t e = 0; e < op->ncells; ++e)
+    {
+      const int64_t cell = L.cell_perm[e];
+      const T cc = c0[cell], rr = rho0[cell];
+      n1[e] = T(-2.0) * beta0[cell] / rr / rr / cc / cc / cc / cc;
+    }
+    T* d_n1;
+    FUSCHK(upload(pool, &d_n1, n1, st));
+    FUSCHK(dalloc_bytes(pool, &m->mn1, n * sizeof(T), true, st));
+    FUSCHK((apply_internal<T, P, OP_MASS>(op, d_n1, ones, static_cast<T*>(m->mn1))));
+  }
   HIPCHK(hipMemsetAsync(m->un, 0, n * sizeof(T), st));
 
   // boundary weights of this rank's facets (diagonal: GLL collocation)
@@ -755,7 +774,7 @@ static int model_setup(fus_model* m, const void* c0_, const void* rho0_, const v
 
 // Setup vectors: m (needs the sharers' contributions, m.scatter_rev(+), Linear.hpp:134), src
 // weights (parked in u_) and abs weights (parked in v_) of this rank's own facets
-static void* setup_halo_vector(fus_model* m, int k) { return k == 0 ? m->m : (k == 1 ? m->u_ : m->v_); }
+static void* setup_halo_vector(fus_model* m, int k) { return k == 0 ? m->m : (k == 1 ? m->mn1 : m->v_); }
 
 template <typename T>
 static int model_setup_finish(fus_model* m)
@@ -765,7 +784,7 @@ static int model_setup_finish(fus_model* m)
   const int64_t n = op->L.n_internal;
   hipLaunchKernelGGL((k_reciprocal<T>), dim3(nblk(n)), dim3(256), 0, st, n,
                      static_cast<const T*>(m->m), static_cast<T*>(m->minv));
-  const bool lossy = m->kind == FUS_LOSSY;
+  const bool lossy = m->kind == FUS_LOSSY || m->kind == FUS_WESTERVELT;
   std::vector<T> src(n), absb(n), src2(lossy ? n : 0);
   HIPCHK(hipMemcpyAsync(src.data(), m->u_, n * sizeof(T), hipMemcpyDeviceToHost, st));
   HIPCHK(hipMemcpyAsync(absb.data(), m->v_, n * sizeof(T), hipMemcpyDeviceToHost, st));
@@ -860,7 +879,7 @@ static StageScalars stage_scalars(const fus_model* m, int i, double t_, double d
   else
     window = 1.0, dwindow = 0.0;
   StageScalars sc;
-  if (m->kind == FUS_LOSSY)
+  if (m->kind == FUS_LOSSY || m->kind == FUS_WESTERVELT)
   {
     // heterogeneous-domain scaling, live in Lossy.hpp:216-220 (factor 2) and its derivative dg
     sc.gval = (double)(window * (T)2.0 * p0 * w0 / s0 * (T)std::cos((double)(w0 * tn)));
@@ -890,6 +909,7 @@ static StageArgs<T> stage_args(fus_model* m, const StageScalars& sc)
   S.bnd_src = static_cast<const T*>(m->d_bsrc), S.bnd_abs = static_cast<const T*>(m->d_babs);
   S.x2 = nullptr, S.coef2 = static_cast<const T*>(m->coef2);
   S.bnd_src2 = static_cast<const T*>(m->d_bsrc2), S.dgval = (T)sc.dgval;
+  S.m0 = static_cast<const T*>(m->m), S.mn1 = static_cast<const T*>(m->mn1);
   return S;
 }
 
@@ -908,7 +928,7 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
   const T* coef = static_cast<const T*>(m->coef);
   {
     ProfScope ps(m->ctx, "stiffness");
-    if (m->kind == FUS_LOSSY)
+    if (m->kind == FUS_LOSSY || m->kind == FUS_WESTERVELT)
     {
       if (i == 0)
         FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 0, 2>(op, G, coef, ustage, b, S)));
@@ -967,6 +987,9 @@ static int stage_end(fus_model* m, int i, double t, double dt)
   const T* minv = static_cast<const T*>(m->minv);
   const T* partial = static_cast<const T*>(op->d_partial);
   const int64_t off = op->L.n_int_pad, nloc = op->L.n_shared_local;
+  // Westervelt: m0 and mn1 on the shared range (nullptr otherwise)
+  const T* m0p = m->mn1 ? static_cast<const T*>(m->m) + off : nullptr;
+  const T* mn1p = m->mn1 ? static_cast<const T*>(m->mn1) + off : nullptr;
   if (nloc > 0)
   {
     ProfScope ps(c, "stage");
@@ -976,17 +999,17 @@ static int stage_end(fus_model* m, int i, double t, double dt)
     case 0:
       hipLaunchKernelGGL((k_shared_stage<T, 0>), grid, blk, 0, st, nloc, m->d_sh_ptr32,
                          m->d_sh_pairs32, partial, minv + off, vn + off, un + off, u0 + off,
-                         v0 + off, u_ + off, v_ + off, adt, bdt);
+                         v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p);
       break;
     case 3:
       hipLaunchKernelGGL((k_shared_stage<T, 3>), grid, blk, 0, st, nloc, m->d_sh_ptr32,
                          m->d_sh_pairs32, partial, minv + off, vn + off, un + off, u0 + off,
-                         v0 + off, u_ + off, v_ + off, adt, bdt);
+                         v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p);
       break;
     default:
       hipLaunchKernelGGL((k_shared_stage<T, 1>), grid, blk, 0, st, nloc, m->d_sh_ptr32,
                          m->d_sh_pairs32, partial, minv + off, vn + off, un + off, u0 + off,
-                         v0 + off, u_ + off, v_ + off, adt, bdt);
+                         v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p);
     }
   }
   if (op->L.n_shared > op->L.n_if_start_pad)
@@ -1001,15 +1024,21 @@ static int stage_end(fus_model* m, int i, double t, double dt)
     {
     case 0:
       hipLaunchKernelGGL((k_stage<T, 0>), dim3(grid), dim3(256), 0, st, n2, b + o2, minv + o2,
-                         vn + o2, un + o2, u0 + o2, v0 + o2, u_ + o2, v_ + o2, adt, bdt);
+                         vn + o2, un + o2, u0 + o2, v0 + o2, u_ + o2, v_ + o2, adt, bdt,
+                         m->mn1 ? static_cast<const T*>(m->m) + o2 : nullptr,
+                         m->mn1 ? static_cast<const T*>(m->mn1) + o2 : nullptr);
       break;
     case 3:
       hipLaunchKernelGGL((k_stage<T, 3>), dim3(grid), dim3(256), 0, st, n2, b + o2, minv + o2,
-                         vn + o2, un + o2, u0 + o2, v0 + o2, u_ + o2, v_ + o2, adt, bdt);
+                         vn + o2, un + o2, u0 + o2, v0 + o2, u_ + o2, v_ + o2, adt, bdt,
+                         m->mn1 ? static_cast<const T*>(m->m) + o2 : nullptr,
+                         m->mn1 ? static_cast<const T*>(m->mn1) + o2 : nullptr);
       break;
     default:
       hipLaunchKernelGGL((k_stage<T, 1>), dim3(grid), dim3(256), 0, st, n2, b + o2, minv + o2,
-                         vn + o2, un + o2, u0 + o2, v0 + o2, u_ + o2, v_ + o2, adt, bdt);
+                         vn + o2, un + o2, u0 + o2, v0 + o2, u_ + o2, v_ + o2, adt, bdt,
+                         m->mn1 ? static_cast<const T*>(m->m) + o2 : nullptr,
+                         m->mn1 ? static_cast<const T*>(m->mn1) + o2 : nullptr);
     }
   }
   HIPCHK(hipGetLastError());
@@ -1124,9 +1153,11 @@ static int d_op_get_geometry(fus_op* op, void* G, void* dJ)
   FUS_DISPATCH(op->dtype, op->P, (op_get_geometry<TT, PP>(op, G, dJ)));
 }
 static int d_model_setup(fus_model* m, const void* c0, const void* rho0, const void* delta0,
-                         int64_t nf, const int32_t* fc, const int32_t* fl, const int32_t* ft)
+                         const void* beta0, int64_t nf, const int32_t* fc, const int32_t* fl,
+                         const int32_t* ft)
 {
-  FUS_DISPATCH(m->op->dtype, m->op->P, (model_setup<TT, PP>(m, c0, rho0, delta0, nf, fc, fl, ft)));
+  FUS_DISPATCH(m->op->dtype, m->op->P,
+               (model_setup<TT, PP>(m, c0, rho0, delta0, beta0, nf, fc, fl, ft)));
 }
 static int d_model_step(fus_model* m, double t, double dt)
 {
@@ -1564,14 +1595,16 @@ int fus_model_create(fus_ctx* c, int kind, fus_op* op, const void* c0, const voi
 {
   if (!c || !op || !c0 || !rho0 || !out)
     return fail(FUS_ERR_ARG, "null argument");
-  if (kind != FUS_LINEAR && kind != FUS_LOSSY)
-    return fail(FUS_ERR_ARG, "only FUS_LINEAR and FUS_LOSSY are implemented");
+  if (kind != FUS_LINEAR && kind != FUS_LOSSY && kind != FUS_WESTERVELT)
+    return fail(FUS_ERR_ARG, "unknown model kind");
   if (kind == FUS_LINEAR && (delta0 || beta0))
     return fail(FUS_ERR_ARG, "delta0/beta0 must be NULL for FUS_LINEAR");
   if (kind == FUS_LOSSY && (!delta0 || beta0))
     return fail(FUS_ERR_ARG, "FUS_LOSSY needs delta0 (and no beta0)");
-  if (kind == FUS_LOSSY && op->nfields < 2)
-    return fail(FUS_ERR_STATE, "FUS_LOSSY needs operator data created with option fields=2");
+  if (kind == FUS_WESTERVELT && (!delta0 || !beta0))
+    return fail(FUS_ERR_ARG, "FUS_WESTERVELT needs delta0 and beta0");
+  if (kind != FUS_LINEAR && op->nfields < 2)
+    return fail(FUS_ERR_STATE, "FUS_LOSSY / FUS_WESTERVELT need operator data created with option fields=2");
   if (nfacets > 0 && (!facet_cells || !facet_local || !facet_tags))
     return fail(FUS_ERR_ARG, "null facet arrays");
   if (!(freq > 0) || !(speed > 0))
@@ -1579,7 +1612,7 @@ int fus_model_create(fus_ctx* c, int kind, fus_op* op, const void* c0, const voi
   HIPCHK(hipSetDevice(c->device));
   std::unique_ptr<fus_model> m(new fus_model());
   m->ctx = c, m->op = op, m->kind = kind, m->freq = freq, m->amp = amp, m->speed = speed;
-  int r = d_model_setup(m.get(), c0, rho0, delta0, nfacets, facet_cells, facet_local, facet_tags);
+  int r = d_model_setup(m.get(), c0, rho0, delta0, beta0, nfacets, facet_cells, facet_local, facet_tags);
   if (r == FUS_OK && !c->local_group)
   {
     // add the sharers' parts of the lumped mass over RCCL, then finish; with the in-process
@@ -1587,6 +1620,8 @@ int fus_model_create(fus_ctx* c, int kind, fus_op* op, const void* c0, const voi
     // weights of interface dofs stay per-rank: each rank adds the term of its own facets to its
     // partial b and the exchange sums them (v_n is identical on all sharers).
     r = d_halo_sum(op, setup_halo_vector(m.get(), 0));
+    if (r == FUS_OK && m->mn1)
+      r = d_halo_sum(op, setup_halo_vector(m.get(), 1));
     if (r == FUS_OK)
       r = d_setup_finish(m.get());
   }
@@ -1634,7 +1669,9 @@ int fus_group_finish_setup(fus_model** ms, int n)
 {
   if (!ms || n < 1)
     return fail(FUS_ERR_ARG, "bad group");
-  FUSCHK(group_halo(ms, n, 0));  // lumped mass only (see fus_model_create)
+  FUSCHK(group_halo(ms, n, 0));  // lumped mass (see fus_model_create)
+  if (ms[0]->mn1)
+    FUSCHK(group_halo(ms, n, 1));  // Westervelt: diagonal of M(nlin1)
   for (int i = 0; i < n; ++i)
     FUSCHK(d_setup_finish(ms[i]));
   return FUS_OK;

@@ -65,6 +65,11 @@ struct StageArgs
   const T* coef2;
   const T* bnd_src2;
   T dgval;
+  // Westervelt (nullptr otherwise): lumped mass m0 and the diagonal of M(nlin1) = M(-2 beta/(rho^2
+  // c^4)); per stage the LHS is m0 + mn1 .* u_n and the RHS gains -mn1 .* v_n^2
+  // (Westervelt.hpp:246-265; the mass operator is diagonal, so M(c) x = diag(M(c) 1) .* x)
+  const T* m0;
+  const T* mn1;
 };
 
 enum
@@ -564,11 +569,34 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
         bv = reinterpret_cast<const V2*>(y_l)[i];
       else
         bv[0] = y_l[2 * i], bv[1] = T(0);
-      mi = ld(S.minv);
-      const V2 kv = bv * mi;
+      // stage inputs v_n (= v0 at stage 0) are needed by every variant below; load once
+      if (STAGE == 0)
+        a0 = ld(S.u0), b0 = ld(S.v0);
+      else
+        w = ld(S.vn);
+      V2 kv;
+      if (NF == 2 && S.mn1)
+      {
+        // Westervelt: kv = (b - mn1 v_n^2) / (m0 + mn1 u_n); u_n of interior dofs is still in x_l
+        const V2 vs = (STAGE == 0) ? b0 : w;
+        V2 us;
+        if (!tail)
+          us = reinterpret_cast<const V2*>(x_l)[i];
+        else
+          us[0] = x_l[2 * i], us[1] = T(0);
+        const V2 m1 = ld(S.mn1);
+        V2 den = ld(S.m0) + m1 * us;
+        if (tail)
+          den[1] = T(1);
+        kv = (bv - m1 * vs * vs) / den;
+      }
+      else
+      {
+        mi = ld(S.minv);
+        kv = bv * mi;
+      }
       if (STAGE == 0)
       {
-        a0 = ld(S.u0), b0 = ld(S.v0);
         st(S.u_, b0 * S.bdt + a0);
         st(S.v_, kv * S.bdt + b0);
         st(S.un, b0 * S.adt + a0);
@@ -576,13 +604,13 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
       }
       else if (STAGE == 3)
       {
-        w = ld(S.vn), au = ld(S.u_), av = ld(S.v_);
+        au = ld(S.u_), av = ld(S.v_);
         st(S.u0, w * S.bdt + au);
         st(S.v0, kv * S.bdt + av);
       }
       else
       {
-        w = ld(S.vn), au = ld(S.u_), av = ld(S.v_), a0 = ld(S.u0), b0 = ld(S.v0);
+        au = ld(S.u_), av = ld(S.v_), a0 = ld(S.u0), b0 = ld(S.v0);
         st(S.u_, w * S.bdt + au);
         st(S.v_, kv * S.bdt + av);
         st(S.un, w * S.adt + a0);
@@ -617,7 +645,8 @@ __global__ void __launch_bounds__(256)
 k_shared_stage(int64_t n, const int32_t* __restrict__ sh_ptr, const int32_t* __restrict__ sh_pairs,
                const T* __restrict__ partial, const T* __restrict__ minv, T* __restrict__ vn,
                T* __restrict__ un, T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ u_,
-               T* __restrict__ v_, T adt, T bdt)
+               T* __restrict__ v_, T adt, T bdt, const T* __restrict__ m0,
+               const T* __restrict__ mn1)
 {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n)
@@ -625,7 +654,14 @@ k_shared_stage(int64_t n, const int32_t* __restrict__ sh_ptr, const int32_t* __r
   T acc = T(0);
   for (int32_t k = sh_ptr[s]; k < sh_ptr[s + 1]; ++k)
     acc += partial[sh_pairs[k]];
-  const T kv = acc * minv[s];
+  T kv;
+  if (mn1)  // Westervelt (see StageArgs): stage inputs u_n, v_n are u0, v0 at stage 0
+  {
+    const T us = (STAGE == 0) ? u0[s] : un[s], vs = (STAGE == 0) ? v0[s] : vn[s];
+    kv = (acc - mn1[s] * vs * vs) / (m0[s] + mn1[s] * us);
+  }
+  else
+    kv = acc * minv[s];
   if (STAGE == 0)
   {
     const T u = u0[s], v = v0[s];
@@ -691,7 +727,8 @@ template <typename T, int STAGE>
 __global__ void __launch_bounds__(256)
 k_stage(int64_t n, const T* __restrict__ b, const T* __restrict__ minv, T* __restrict__ vn,
         T* __restrict__ un, T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ u_,
-        T* __restrict__ v_, T adt, T bdt)
+        T* __restrict__ v_, T adt, T bdt, const T* __restrict__ m0 = nullptr,
+        const T* __restrict__ mn1 = nullptr)
 {
   typedef T V __attribute__((ext_vector_type(16 / sizeof(T))));
   constexpr int VW = 16 / sizeof(T);
@@ -699,7 +736,19 @@ k_stage(int64_t n, const T* __restrict__ b, const T* __restrict__ minv, T* __res
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
        i += (int64_t)gridDim.x * blockDim.x)
   {
-    const V kv = reinterpret_cast<const V*>(b)[i] * reinterpret_cast<const V*>(minv)[i];
+    V kv;
+    if (mn1)  // Westervelt (see StageArgs); padding slots have m0 = mn1 = 0 and b = 0
+    {
+      const V us = reinterpret_cast<const V*>(STAGE == 0 ? u0 : un)[i];
+      const V vs = reinterpret_cast<const V*>(STAGE == 0 ? v0 : vn)[i];
+      const V m1 = reinterpret_cast<const V*>(mn1)[i];
+      V den = reinterpret_cast<const V*>(m0)[i] + m1 * us;
+      for (int k = 0; k < VW; ++k)
+        den[k] = (den[k] != T(0)) ? den[k] : T(1);
+      kv = (reinterpret_cast<const V*>(b)[i] - m1 * vs * vs) / den;
+    }
+    else
+      kv = reinterpret_cast<const V*>(b)[i] * reinterpret_cast<const V*>(minv)[i];
     if (STAGE == 0)
     {
       const V u = reinterpret_cast<const V*>(u0)[i], v = reinterpret_cast<const V*>(v0)[i];

@@ -5,6 +5,7 @@ mirror of the reference's operator/model interface."""
 from . import tables  # noqa: F401
 from ._abi import Context, FusError, layout_check  # noqa: F401
 from .mesh import BoxMesh, CellFunction, FacetTags, Function, FunctionSpace, tag_box_boundary  # noqa: F401
-from .models import (LinearSpectralExplicit, LossySpectralExplicit, compute_diffusivity_of_sound,  # noqa: F401
+from .models import (LinearSpectralExplicit, LossySpectralExplicit, WesterveltSpectralExplicit,  # noqa: F401
+                     compute_diffusivity_of_sound,
                      group_finish_setup, group_rk4_steps)
 from .operators import MassSpectral3D, SpectralOperatorData, StiffnessSpectral3D  # noqa: F401

@@ -22,7 +22,7 @@ class _SpectralExplicit:
 
     _kind = _abi.FUS_LINEAR
 
-    def _create(self, mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt, V, ctx):
+    def _create(self, mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt, V, ctx, beta0=None):
         if rk_order != 4:
             raise _abi.FusError("only the classical RK4 scheme (rk_order=4) is offloaded")
         self.mesh, self.dt = mesh, dt
@@ -34,12 +34,13 @@ class _SpectralExplicit:
         c0a = np.ascontiguousarray(_array(c0), dtype=dt_)
         rhoa = np.ascontiguousarray(_array(rho0), dtype=dt_)
         dla = None if delta0 is None else np.ascontiguousarray(_array(delta0), dtype=dt_)
+        bta = None if beta0 is None else np.ascontiguousarray(_array(beta0), dtype=dt_)
         cells = np.ascontiguousarray(meshtags.cells, dtype=np.int32)
         lf = np.ascontiguousarray(meshtags.local_facets, dtype=np.int32)
         tags = np.ascontiguousarray(meshtags.values, dtype=np.int32)
         self.h = C.c_void_p()
         check(lib().fus_model_create(self.ctx.h, C.c_int(self._kind), self.data.h, ptr(c0a), ptr(rhoa),
-                                     ptr(dla), None, C.c_int64(len(cells)), ptr(cells), ptr(lf), ptr(tags),
+                                     ptr(dla), ptr(bta), C.c_int64(len(cells)), ptr(cells), ptr(lf), ptr(tags),
                                      C.c_double(self.freq), C.c_double(self.p0), C.c_double(self.s0),
                                      C.byref(self.h)))
         self.u_n = Function(self.V, dt_)
@@ -121,6 +122,18 @@ class LossySpectralExplicit(_SpectralExplicit):
     def __init__(self, mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order=4, dt=None, V=None,
                  ctx: Context | None = None):
         self._create(mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt, V, ctx)
+
+
+class WesterveltSpectralExplicit(_SpectralExplicit):
+    """``WesterveltSpectralExplicit(mesh, meshtags, k, c0, rho0, delta0, beta0, freq0, p0, s0,
+    rk_order, dt)`` (python/src/fenicsxfus/_westervelt.py:21-23; C++ ``WesterveltSpectral3D``,
+    Westervelt.hpp:58-67).  ``beta0`` = coefficient of nonlinearity (DG0)."""
+
+    _kind = _abi.FUS_WESTERVELT
+
+    def __init__(self, mesh, meshtags, k, c0, rho0, delta0, beta0, freq0, p0, s0, rk_order=4, dt=None, V=None,
+                 ctx: Context | None = None):
+        self._create(mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt, V, ctx, beta0=beta0)
 
 
 def compute_diffusivity_of_sound(w0: float, c0: float, alpha: float) -> float:

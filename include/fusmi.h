@@ -143,7 +143,11 @@ int fus_op_set_neighbours(fus_op* op, int nneigh, const int32_t* ranks, const in
  * (Lossy.hpp:231-232), run as ONE pass of the block kernel (both share G); absorbing term on every
  * listed facet, dg source term and the delta/(rho c^3) boundary mass term as in
  * BM7-SC1/forms.py:37-42; source scaling 2 W p0 w0/s0 as live in Lossy.hpp:216-220.  The operator
- * data must have been created with option "fields" = 2.  beta0 is reserved for FUS_WESTERVELT. */
+ * data must have been created with option "fields" = 2.
+ * FUS_WESTERVELT replaces WesterveltSpectral3D (Westervelt.hpp:58-193): beta0 = coefficient of
+ * nonlinearity per cell.  The per-stage mass re-assembly m = m0 + M(nlin1) u_n and the RHS term
+ * M(nlin2)(v_n^2) (Westervelt.hpp:246-265) are diagonal (M(c) x = diag(M(c) 1) .* x), so they fold
+ * into the fused stage update: kv = (b - mn1 v_n^2) / (m0 + mn1 u_n), mn1 = M(-2 beta/(rho^2 c^4)) 1. */
 int fus_model_create(fus_ctx* ctx, int kind, fus_op* op, const void* c0, const void* rho0,
                      const void* delta0, const void* beta0, int64_t nfacets,
                      const int32_t* facet_cells, const int32_t* facet_local,

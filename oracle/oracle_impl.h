@@ -600,6 +600,103 @@ int64_t FN(orc_lossy_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
   return step;
 }
 
+
+/* Westervelt.hpp:196-373: init + rk4 of the nonlinear (Westervelt) model.  f1 (:216-281) is the
+ * lossy f1 plus two diagonal mass actions per stage: the LHS is re-assembled as
+ * m = m0 + M(nlin1) u_n  (:249-257, nlin1 = -2 beta/(rho^2 c^4), :185) and the RHS gains
+ * M(nlin2) (v_n .* v_n)  (:246-247, :263, nlin2 = +2 beta/(rho^2 c^4), :186).  detJ is the scaled
+ * Jacobian determinant the mass operator uses (spectral_op.hpp:80-81).  Other arguments as
+ * orc_lossy_rk4 (m0 = its m). */
+int64_t FN(orc_westervelt_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
+                               const int32_t* tensor_dofmap, const REAL* G, const REAL* detJ,
+                               const REAL* dphi, const REAL* lin_coeff, const REAL* att_coeff,
+                               const REAL* nlin1_coeff, const REAL* nlin2_coeff, const REAL* m0,
+                               const REAL* src, const REAL* absb, const REAL* src2, double freq_,
+                               double p0_, double s0_, double t0, double tf_, double dt_,
+                               REAL* u_n, REAL* v_n)
+{
+  const REAL freq = (REAL)freq_, p0 = (REAL)p0_, s0 = (REAL)s0_;
+  const REAL w0 = (REAL)(2 * M_PI * freq_);
+  const REAL period = (REAL)(1.0 / freq_), window_length = (REAL)4.0;
+  const size_t nb = sizeof(REAL) * ndofs;
+  REAL *u_ = (REAL*)malloc(nb), *v_ = (REAL*)malloc(nb), *un = (REAL*)malloc(nb),
+       *vn = (REAL*)malloc(nb), *u0 = (REAL*)malloc(nb), *v0 = (REAL*)malloc(nb),
+       *ku = (REAL*)malloc(nb), *kv = (REAL*)malloc(nb), *b = (REAL*)malloc(nb),
+       *uw = (REAL*)malloc(nb), *vw = (REAL*)malloc(nb), *ww = (REAL*)malloc(nb),
+       *m = (REAL*)malloc(nb);
+  REAL t = (REAL)t0, tf = (REAL)tf_, dt = (REAL)dt_;
+  int64_t step = 0;
+  FN(k_copy)(ndofs, u_n, u_), FN(k_copy)(ndofs, v_n, v_);
+  FN(k_copy)(ndofs, u_, ku), FN(k_copy)(ndofs, v_, kv);
+  const REAL a_runge[4] = {0.0, 0.5, 0.5, 1.0};
+  const REAL b_runge[4] = {(REAL)(1.0 / 6.0), (REAL)(1.0 / 3.0), (REAL)(1.0 / 3.0),
+                           (REAL)(1.0 / 6.0)};
+  const REAL c_runge[4] = {0.0, 0.5, 0.5, 1.0};
+  while (t < tf)
+  {
+    dt = (dt < tf - t) ? dt : tf - t;
+    FN(k_copy)(ndofs, u_, u0), FN(k_copy)(ndofs, v_, v0);
+    for (int i = 0; i < 4; i++)
+    {
+      FN(k_copy)(ndofs, u0, un), FN(k_copy)(ndofs, v0, vn);
+      FN(k_axpy)(ndofs, un, dt * a_runge[i], ku, un);
+      FN(k_axpy)(ndofs, vn, dt * a_runge[i], kv, vn);
+      const REAL tn = t + c_runge[i] * dt;
+      FN(k_copy)(ndofs, vn, ku);
+      {
+        REAL window, dwindow;
+        if (tn < period * window_length)
+        {
+          window = (REAL)(0.5 * (1.0 - cos((double)(freq * (REAL)M_PI * tn / window_length))));
+          dwindow = (REAL)(0.5 * M_PI) * freq / window_length
+                    * (REAL)sin((double)(freq * (REAL)M_PI * tn / window_length));
+        }
+        else
+          window = 1.0, dwindow = 0.0;
+        const REAL gval = window * (REAL)2.0 * p0 * w0 / s0 * (REAL)cos((double)(w0 * tn));
+        const REAL dgval = dwindow * (REAL)2.0 * p0 * w0 / s0 * (REAL)cos((double)(w0 * tn))
+                           - window * (REAL)2.0 * p0 * w0 * w0 / s0 * (REAL)sin((double)(w0 * tn));
+        FN(k_copy)(ndofs, un, uw);
+        FN(k_copy)(ndofs, vn, vw);
+        for (int64_t k = 0; k < ndofs; ++k)
+          ww[k] = vw[k] * vw[k];
+        /* LHS (:249-257) */
+        for (int64_t k = 0; k < ndofs; ++k)
+          m[k] = 0;
+        FN(orc_mass)(tdim, ncells, N, tensor_dofmap, detJ, nlin1_coeff, uw, m);
+        for (int64_t k = 0; k < ndofs; ++k)
+          m[k] = m0[k] + m[k];
+        /* RHS (:260-265) */
+        for (int64_t k = 0; k < ndofs; ++k)
+          b[k] = 0;
+        if (tdim == 3)
+        {
+          FN(orc_stiffness3d)(ncells, N, tensor_dofmap, G, dphi, lin_coeff, uw, b);
+          FN(orc_stiffness3d)(ncells, N, tensor_dofmap, G, dphi, att_coeff, vw, b);
+        }
+        else
+        {
+          FN(orc_stiffness2d)(ncells, N, tensor_dofmap, G, dphi, lin_coeff, uw, b);
+          FN(orc_stiffness2d)(ncells, N, tensor_dofmap, G, dphi, att_coeff, vw, b);
+        }
+        FN(orc_mass)(tdim, ncells, N, tensor_dofmap, detJ, nlin2_coeff, ww, b);
+        for (int64_t k = 0; k < ndofs; ++k)
+          b[k] += gval * src[k] - absb[k] * vw[k] + dgval * src2[k];
+        for (int64_t k = 0; k < ndofs; ++k)
+          kv[k] = b[k] / m[k];
+      }
+      FN(k_axpy)(ndofs, u_, dt * b_runge[i], ku, u_);
+      FN(k_axpy)(ndofs, v_, dt * b_runge[i], kv, v_);
+    }
+    t += dt;
+    step += 1;
+  }
+  FN(k_copy)(ndofs, u_, u_n), FN(k_copy)(ndofs, v_, v_n);
+  free(u_), free(v_), free(un), free(vn), free(u0), free(v0), free(ku), free(kv), free(b), free(uw),
+      free(vw), free(ww), free(m);
+  return step;
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

@@ -227,6 +227,36 @@ def test_lossy_rk4_vs_oracle(orc, ctx, hetero):
     model.close(), lm.close()
 
 
+def test_westervelt_rk4_vs_oracle(orc, ctx):
+    # WesterveltSpectral3D (Westervelt.hpp:58-373): lossy + per-stage nonlinear mass terms
+    L = 0.012
+    P, n = 4, (6, 6, 6)
+    pr, c, rho, tags = _linear_setup(orc, ctx, n, P, [L, L, L], perturb=0.1, hetero=True)
+    f0, p0, s0 = 0.5e6, 6.0e6, 1500.0     # high drive so the nonlinear terms matter in 20 steps
+    w0 = 2 * np.pi * f0
+    nc = pr.mesh.num_cells
+    delta = np.full(nc, fa.compute_diffusivity_of_sound(w0, 1500.0, 0.2))
+    beta = np.where(c > 2000.0, 6.0, 3.5)
+    dt = 0.5 * (L / n[0]) / (c.max() * P**2)
+    nsteps = 20
+    m, src, absb, src2, lin, att = pr.lossy_model_vectors(c, rho, delta, tags)
+    n1 = -2.0 * beta / rho**2 / c**4
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    ns = orc.westervelt_rk4(3, pr.N, pr.dm, pr.G, pr.detJ, pr.D, lin, att, n1, -n1, m, src, absb, src2, f0, p0, s0,
+                            0.0, nsteps * dt * (1 - 1e-9), dt, u, v)
+    assert ns == nsteps
+    model = fa.WesterveltSpectralExplicit(pr.mesh, tags, P, c, rho, delta, beta, f0, p0, s0, 4, dt, V=pr.V, ctx=ctx)
+    model.init()
+    un, vn, _ = model.rk(0.0, nsteps * dt * (1 - 1e-9))
+    assert relmax(un.x.array, u) < TOL_RK and relmax(vn.x.array, v) < TOL_RK
+    # the nonlinearity is visible: differs from the lossy solution beyond tolerance
+    lm = fa.LossySpectralExplicit(pr.mesh, tags, P, c, rho, delta, f0, p0, s0, 4, dt, V=pr.V, ctx=ctx)
+    lm.init()
+    ul, _, _ = lm.rk(0.0, nsteps * dt * (1 - 1e-9))
+    assert relmax(un.x.array, ul.x.array) > 1e-7
+    model.close(), lm.close()
+
+
 def test_plane_wave_vs_analytical_gpu(orc, ctx):
     # python/tests/test_linearspectral_1d.py:12-107 (degree 4, epw 4): L2 error < 1e-3
     f0, c0, rho0, L, degree, epw = 10.0, 1.0, 4.0, 1.0, 4, 4

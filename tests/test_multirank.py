@@ -171,6 +171,46 @@ def test_slabs_in_process_gpu(orc, size):
 
 
 @pytest.mark.gpu
+def test_westervelt_slabs_in_process_gpu(orc):
+    # the nonlinear model across 2 slabs: m0 and the M(nlin1) diagonal are summed over the sharers
+    pr = Problem(orc, N_GLOBAL, P, hi=HI, perturb=0.1)
+    c, rho = material(pr.mesh)
+    tags = fa.tag_box_boundary(pr.mesh)
+    w0 = 2 * np.pi * F0
+    delta, beta = fa.compute_diffusivity_of_sound(w0, 1500.0, 0.2), 3.5
+    m, src, absb, src2, lin, att = pr.lossy_model_vectors(c, rho, delta, tags)
+    n1 = -2.0 * beta / rho**2 / c**4
+    u_ref, v_ref = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    dt = dt_value()
+    p0 = 6.0e6
+    orc.westervelt_rk4(3, pr.N, pr.dm, pr.G, pr.detJ, pr.D, lin, att, n1, -n1, m, src, absb, src2, F0, p0, S0, 0.0,
+                       NSTEPS * dt * (1 + 1e-12), dt, u_ref, v_ref)
+    size = 2
+    ctxs = [fa.Context(0) for _ in range(size)]
+    fa.Context.init_local_group(ctxs)
+    models, offs = [], []
+    for r in range(size):
+        mesh = fa.BoxMesh([0, 0, 0], HI, N_GLOBAL, rank=r, size=size, perturb=0.1)
+        V = fa.FunctionSpace(mesh, P)
+        cr, rr = material(mesh)
+        nc = mesh.num_cells
+        models.append(fa.WesterveltSpectralExplicit(mesh, fa.tag_box_boundary(mesh), P, cr, rr, np.full(nc, delta),
+                                                    np.full(nc, beta), F0, p0, S0, 4, dt, V=V, ctx=ctxs[r]))
+        offs.append(V.global_offset)
+    fa.group_finish_setup(models)
+    for mdl in models:
+        mdl.init()
+    fa.group_rk4_steps(models, 0.0, dt, NSTEPS)
+    for r, mdl in enumerate(models):
+        n = mdl.data.ndofs
+        u = mdl.u_sol().x.array
+        assert np.abs(u - u_ref[offs[r]:offs[r] + n]).max() < 1e-10 * np.abs(u_ref).max()
+        mdl.close()
+    for cx in ctxs:
+        cx.close()
+
+
+@pytest.mark.gpu
 def test_rccl_binding_selftest():
     # grouped ncclSend/ncclRecv (to the own rank) through the dlopen'ed RCCL on the library stream
     c = fa.Context(0)

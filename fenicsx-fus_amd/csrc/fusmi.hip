@@ -126,7 +126,9 @@ struct fus_ctx
   int deterministic = 0;  // 1: conflict-free rounds (bitwise reproducible); 0: LDS atomics
   int fields = 1;         // operator inputs per block pass the ops are sized for (2: Lossy)
   int geometry = 0;       // 0: auto (per-cell factors when every cell is affine), 1: always stream G
-  int block_elems = 32, waves = 4;  // measured best on MI355X at p=4 fp64 (profiles/r01_block_sweep.txt)
+  // 0 = auto: 32 elements / 4 waves when G is streamed, 16 / 2 on the affine path (measured best
+  // on MI355X at p=4 fp64, profiles/r01_block_sweep.txt)
+  int block_elems = 0, waves = 0;
   bool prof = false;
   std::map<std::string, Prof> profs;
   ncclComm_t comm = nullptr;
@@ -1210,11 +1212,39 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
             0.125 * (op->dtype == FUS_F64 ? reinterpret_cast<const double*>(op->h_geom_x.data())[k]
                                           : (double)reinterpret_cast<const float*>(op->h_geom_x.data())[k]);
       }
+  // will the per-cell (affine) geometry path be taken?  (same test as k_geometry_affine, on the host
+  // copy: every vertex of every cell on the parallelepiped spanned by vertices 0, 1, 2, 4)
+  bool affine_mesh = c->geometry == 0;
+  for (int64_t cidx = 0; cidx < op->ncells && affine_mesh; ++cidx)
+  {
+    double cd[8][3], h2 = 0, e2 = 0;
+    for (int v = 0; v < 8; ++v)
+      for (int j = 0; j < 3; ++j)
+      {
+        const size_t k = 3 * (size_t)op->h_geom_dm[cidx * 8 + v] + j;
+        cd[v][j] = op->dtype == FUS_F64 ? reinterpret_cast<const double*>(op->h_geom_x.data())[k]
+                                        : (double)reinterpret_cast<const float*>(op->h_geom_x.data())[k];
+      }
+    for (int v = 0; v < 8; ++v)
+      for (int i = 0; i < 3; ++i)
+      {
+        const double e0 = cd[1][i] - cd[0][i], e1 = cd[2][i] - cd[0][i], e4 = cd[4][i] - cd[0][i];
+        const double d = cd[v][i] - (cd[0][i] + (v & 1) * e0 + ((v >> 1) & 1) * e1 + (v >> 2) * e4);
+        e2 = std::max(e2, d * d);
+        if (v == 0)
+          h2 += e0 * e0 + e1 * e1 + e4 * e4;
+      }
+    const double tol = op->dtype == FUS_F64 ? 1e-12 : 1e-6;
+    if (std::sqrt(e2 / h2) > 0.5 * tol)
+      affine_mesh = false;
+  }
+  const int be0 = c->block_elems > 0 ? c->block_elems : (affine_mesh ? 16 : 32);
+  const int waves = c->waves > 0 ? c->waves : (affine_mesh ? 2 : 4);
   // blocks must fit the CU's 160 KB of LDS: halve the block size until they do
-  for (int be = c->block_elems;; be = (be + 1) / 2)
+  for (int be = be0;; be = (be + 1) / 2)
   {
     std::string err = build_layout(op->L, op->P, op->ncells, op->ndofs, op->h_dofmap.data(),
-                                   cen.data(), be, c->waves, force_shared);
+                                   cen.data(), be, waves, force_shared);
     const bool too_big = err.empty() ? op->L.lds_bytes(op->ts, op->nfields) + 64 > 160 * 1024
                                      : err.find("65535") != std::string::npos;
     if (too_big && be > 1)
@@ -1288,14 +1318,14 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
     return fail(FUS_ERR_ARG, "null argument");
   if (!strcmp(key, "block_elems"))
   {
-    if (value < 1 || value > 4096)
+    if (value < 0 || value > 4096)
       return fail(FUS_ERR_ARG, "block_elems out of range");
     c->block_elems = (int)value;
   }
   else if (!strcmp(key, "waves"))
   {
-    if (value != 1 && value != 2 && value != 4 && value != 8)
-      return fail(FUS_ERR_ARG, "waves must be 1, 2, 4 or 8");
+    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
+      return fail(FUS_ERR_ARG, "waves must be 0 (auto), 1, 2, 4 or 8");
     c->waves = (int)value;
   }
   else if (!strcmp(key, "deterministic"))

@@ -275,15 +275,13 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
       F1[a] = cf * (G6[1] * w0 + G6[3] * w1 + G6[4] * w2);
       F2[a] = cf * (G6[2] * w0 + G6[4] * w1 + G6[5] * w2);
     }
+    // transposed contractions (spectral_op.hpp:222-238); the index-1 and index-2 parts reuse ONE
+    // exchange tile one after the other (LDS footprint per wave halves -> more blocks per CU)
     FUS_WAVE_SYNC();
 #pragma unroll
     for (int a = 0; a < N; ++a)
-    {
       sA[a * N2 + p] = F1[a];
-      sB[a * N2 + p] = F2[a];
-    }
     FUS_WAVE_SYNC();
-    // transposed contractions (spectral_op.hpp:222-238)
 #pragma unroll
     for (int a = 0; a < N; ++a)
     {
@@ -293,10 +291,21 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
         acc += Dk.d[q * N + a] * F0[q];
 #pragma unroll
       for (int j = 0; j < N; ++j)
-      {
         acc += Dcb[j] * sA[a * N2 + j * N + c];
-        acc += Dcc[j] * sB[a * N2 + b * N + j];
-      }
+      Y[a] = acc;
+    }
+    FUS_WAVE_SYNC();
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      sA[a * N2 + p] = F2[a];
+    FUS_WAVE_SYNC();
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      T acc = Y[a];
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        acc += Dcc[j] * sA[a * N2 + b * N + j];
       Y[a] = acc;
     }
   }
@@ -342,7 +351,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   T* y_l = x_l + A.lds_nloc;
   T* x2_l = y_l + A.lds_nloc;                               // second input (NF == 2 only)
   T* scratch = x2_l + (NF == 2 ? A.lds_nloc : 0);
-  T* D_l = scratch + (size_t)A.waves * EPW * 2 * Nd;      // derivative table
+  T* D_l = scratch + (size_t)A.waves * EPW * Nd;           // derivative table
   T* cf_l = D_l + N2;                                       // per-element coefficient(s)
   T* cf2_l = cf_l + A.lds_nelem;
   T* gc_l = cf2_l + (NF == 2 ? A.lds_nelem : 0);            // affine cells: 6 G + 1 detJ per element
@@ -477,8 +486,8 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     }
   }
 
-  T* sA = scratch + (size_t)(wave * EPW + (active ? s : 0)) * 2 * Nd;
-  T* sB = sA + Nd;
+  T* sA = scratch + (size_t)(wave * EPW + (active ? s : 0)) * Nd;
+  T* sB = sA;  // single exchange tile per element slot
 
   // lane-dependent rows/columns of the derivative table (tiny, cache resident)
   __syncthreads();

@@ -62,7 +62,7 @@ struct Layout
   {
     const size_t ne = ((size_t)max_nelem + 7) & ~(size_t)7;
     return (size_t)(1 + nfields) * ((max_nloc + 1) & ~1) * sizeofT   // x_l (, x2_l), y_l
-           + (size_t)slots * 2 * Nd * sizeofT            // per-element exchange tiles
+           + (size_t)slots * Nd * sizeofT                // per-element exchange tile
            + (size_t)N * N * sizeofT + nfields * ne * sizeofT  // derivative table, coefficients
            + (affine ? (7 * ne + 8) * sizeofT : 0)             // per-cell geometry, 1-D weights
            + ne * Nd * 2                                 // local dofmaps

@@ -48,8 +48,9 @@ int fus_version(void);
 int fus_init(int device, fus_ctx** ctx);
 int fus_finalize(fus_ctx* ctx);
 int fus_synchronize(fus_ctx* ctx);
-/* Tunables, set before fus_op_create: "block_elems" (elements per LDS block, default 32),
- * "waves" (waves per workgroup, default 4), "geometry" (0 auto | 1 always stream the
+/* Tunables, set before fus_op_create: "block_elems" (elements per LDS block) and "waves"
+ * (waves per workgroup; 1, 2, 4 or 8): default 0 = auto (32 / 4 when G is streamed, 16 / 2 on the
+ * affine path), "geometry" (0 auto | 1 always stream the
  * per-point factors), "fields" (1 | 2: operator inputs the block kernel
  * stages per pass; 2 is required by FUS_LOSSY), "deterministic" (1: elements accumulate in
  * conflict-free rounds, results bitwise reproducible; 0 (default): LDS floating-point atomics, the

@@ -303,5 +303,5 @@ def test_full_size_properties(orc, ctx):
     mm = d.mass(np.ones(n), np.full(nc, 1.0), np.zeros(n))
     assert abs(mm.sum() - L**3) < 1e-12 * L**3
     info = d.info()
-    assert info["nblocks"] == 262144 // 32 and info["shapes"] == 27   # default 32-element blocks
+    assert d.is_affine() and info["nblocks"] == 262144 // 16 and info["shapes"] == 27   # affine default: 16-element blocks
     d.close()

@@ -123,6 +123,8 @@ struct fus_ctx
 {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t comm_stream = nullptr;            // RCCL exchange, overlapped with local shared dofs
+  hipEvent_t ev_packed = nullptr, ev_recv = nullptr;
   int deterministic = 0;  // 1: conflict-free rounds (bitwise reproducible); 0: LDS atomics
   int fields = 1;         // operator inputs per block pass the ops are sized for (2: Lossy)
   int geometry = 0;       // 0: auto (per-cell factors when every cell is affine), 1: always stream G
@@ -140,9 +142,7 @@ struct Neigh
 {
   int rank;
   int64_t count;
-  int32_t* d_idx = nullptr;  // internal dof indices
-  void* d_send = nullptr;
-  void* d_recv = nullptr;
+  int64_t off;  // first entry of this neighbour in the send / receive buffers
 };
 
 struct fus_op
@@ -172,9 +172,11 @@ struct fus_op
   int32_t* d_xdm = nullptr;
   // neighbours (multi-GPU)
   std::vector<Neigh> neigh;
-  int32_t* d_uidx = nullptr;  // unique interface dofs (internal)
-  int64_t n_uidx = 0;
-  void* d_own = nullptr;
+  // halo buffers: concatenated neighbour lists (ascending rank), one send and one receive buffer;
+  // unique interface dofs with, per dof, its addends in ascending rank order (-1 = own partial)
+  int64_t n_halo = 0, n_uidx = 0;
+  int32_t *d_pack_idx = nullptr, *d_uidx = nullptr, *d_uptr = nullptr, *d_usrc = nullptr;
+  void *d_sendbuf = nullptr, *d_recvbuf = nullptr;
 };
 
 struct fus_model
@@ -339,16 +341,15 @@ static int halo_pack(fus_op* op, const T* vec)
 {
   if (op->neigh.empty())
     return FUS_OK;
-  hipStream_t st = op->ctx->stream;
-  for (auto& nb : op->neigh)
-    hipLaunchKernelGGL((k_pack<T>), dim3(nblk(nb.count)), dim3(256), 0, st, nb.count, nb.d_idx, vec,
-                       static_cast<T*>(nb.d_send));
-  hipLaunchKernelGGL((k_pack<T>), dim3(nblk(op->n_uidx)), dim3(256), 0, st, op->n_uidx, op->d_uidx,
-                     vec, static_cast<T*>(op->d_own));
+  fus_ctx* c = op->ctx;
+  hipLaunchKernelGGL((k_pack<T>), dim3(nblk(op->n_halo)), dim3(256), 0, c->stream, op->n_halo,
+                     op->d_pack_idx, vec, static_cast<T*>(op->d_sendbuf));
   HIPCHK(hipGetLastError());
+  HIPCHK(hipEventRecord(c->ev_packed, c->stream));
   return FUS_OK;
 }
 
+// grouped send/recv with every neighbour on the comm stream, ordered after the pack by an event
 static int halo_exchange_rccl(fus_op* op)
 {
   fus_ctx* c = op->ctx;
@@ -357,13 +358,17 @@ static int halo_exchange_rccl(fus_op* op)
   if (!c->comm)
     return fail(FUS_ERR_STATE, "neighbours set but fus_comm_init was not called");
   const ncclDataType_t dt = op->ts == 8 ? ncclDouble : ncclFloat;
+  HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_packed, 0));
   NCCLCHK(g_rccl.GroupStart());
   for (auto& nb : op->neigh)
   {
-    NCCLCHK(g_rccl.Send(nb.d_send, nb.count, dt, nb.rank, c->comm, c->stream));
-    NCCLCHK(g_rccl.Recv(nb.d_recv, nb.count, dt, nb.rank, c->comm, c->stream));
+    NCCLCHK(g_rccl.Send(static_cast<char*>(op->d_sendbuf) + nb.off * op->ts, nb.count, dt, nb.rank,
+                        c->comm, c->comm_stream));
+    NCCLCHK(g_rccl.Recv(static_cast<char*>(op->d_recvbuf) + nb.off * op->ts, nb.count, dt, nb.rank,
+                        c->comm, c->comm_stream));
   }
   NCCLCHK(g_rccl.GroupEnd());
+  HIPCHK(hipEventRecord(c->ev_recv, c->comm_stream));
   return FUS_OK;
 }
 
@@ -373,29 +378,16 @@ static int halo_unpack(fus_op* op, T* vec)
   fus_ctx* c = op->ctx;
   if (op->neigh.empty())
     return FUS_OK;
-  hipStream_t st = c->stream;
-  hipLaunchKernelGGL((k_zero_at<T>), dim3(nblk(op->n_uidx)), dim3(256), 0, st, op->n_uidx,
-                     op->d_uidx, vec);
-  bool own_added = false;
-  for (auto& nb : op->neigh)  // sorted by rank at set_neighbours
-  {
-    if (!own_added && nb.rank > c->rank)
-    {
-      hipLaunchKernelGGL((k_add_at<T>), dim3(nblk(op->n_uidx)), dim3(256), 0, st, op->n_uidx,
-                         op->d_uidx, static_cast<const T*>(op->d_own), vec);
-      own_added = true;
-    }
-    hipLaunchKernelGGL((k_add_at<T>), dim3(nblk(nb.count)), dim3(256), 0, st, nb.count, nb.d_idx,
-                       static_cast<const T*>(nb.d_recv), vec);
-  }
-  if (!own_added)
-    hipLaunchKernelGGL((k_add_at<T>), dim3(nblk(op->n_uidx)), dim3(256), 0, st, op->n_uidx,
-                       op->d_uidx, static_cast<const T*>(op->d_own), vec);
+  if (!c->local_group)
+    HIPCHK(hipStreamWaitEvent(c->stream, c->ev_recv, 0));
+  hipLaunchKernelGGL((k_unpack_ordered<T>), dim3(nblk(op->n_uidx)), dim3(256), 0, c->stream,
+                     op->n_uidx, op->d_uidx, op->d_uptr, op->d_usrc,
+                     static_cast<const T*>(op->d_recvbuf), vec);
   HIPCHK(hipGetLastError());
   return FUS_OK;
 }
 
-// RCCL transport: the three phases back to back on the compute stream
+// RCCL transport: the three phases back to back
 template <typename T>
 static int halo_sum(fus_op* op, T* vec)
 {
@@ -430,8 +422,13 @@ static int halo_exchange_local(fus_op** ops, int n)
           back = &pn;
       if (!back || back->count != nb.count)
         return fail(FUS_ERR_STATE, "asymmetric neighbour lists");
-      HIPCHK(hipMemcpy(back->d_recv, nb.d_send, nb.count * ops[i]->ts, hipMemcpyDeviceToDevice));
+      HIPCHK(hipMemcpyAsync(static_cast<char*>(peer->d_recvbuf) + back->off * peer->ts,
+                            static_cast<const char*>(ops[i]->d_sendbuf) + nb.off * ops[i]->ts,
+                            nb.count * ops[i]->ts, hipMemcpyDeviceToDevice, ops[i]->ctx->stream));
     }
+  // device-to-device copies need not block the host: wait for them before anyone unpacks
+  for (int i = 0; i < n; ++i)
+    HIPCHK(hipStreamSynchronize(ops[i]->ctx->stream));
   return FUS_OK;
 }
 
@@ -1016,6 +1013,7 @@ static int stage_end(fus_model* m, int i, double t, double dt)
   }
   if (op->L.n_shared > op->L.n_if_start_pad)
   {
+    // (the rank-local shared dofs above ran while the interface planes were in flight)
     FUSCHK(halo_unpack<T>(op, b));
     ProfScope ps(c, "stage");
     // interface range of the internal vectors; start and length are multiples of 16
@@ -1286,6 +1284,9 @@ int fus_init(int device, fus_ctx** out)
   auto* c = new fus_ctx();
   c->device = device;
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&c->ev_recv, hipEventDisableTiming));
   *out = c;
   return FUS_OK;
 }
@@ -1301,6 +1302,9 @@ int fus_finalize(fus_ctx* c)
       (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
   if (c->comm)
     g_rccl.CommDestroy(c->comm);
+  (void)hipStreamSynchronize(c->comm_stream);
+  (void)hipEventDestroy(c->ev_packed), (void)hipEventDestroy(c->ev_recv);
+  (void)hipStreamDestroy(c->comm_stream);
   (void)hipStreamDestroy(c->stream);
   delete c;
   return FUS_OK;
@@ -1464,9 +1468,9 @@ int fus_op_destroy(fus_op* op)
   (void)hipStreamSynchronize(op->ctx->stream);
   for (void* q : op->allocs)
     (void)hipFree(q);
-  for (auto& nb : op->neigh)
-    (void)hipFree(nb.d_idx), (void)hipFree(nb.d_send), (void)hipFree(nb.d_recv);
-  (void)hipFree(op->d_uidx), (void)hipFree(op->d_own);
+  for (void* q : {(void*)op->d_pack_idx, (void*)op->d_uidx, (void*)op->d_uptr, (void*)op->d_usrc,
+                  op->d_sendbuf, op->d_recvbuf})
+    (void)hipFree(q);
   delete op;
   return FUS_OK;
 }
@@ -1586,34 +1590,69 @@ int fus_op_set_neighbours(fus_op* op, int nneigh, const int32_t* ranks, const in
   for (int k = 0; k < nneigh; ++k)
     off[k + 1] = off[k] + counts[k], order.emplace_back(ranks[k], k);
   std::sort(order.begin(), order.end());
-  std::vector<int32_t> uniq;
+  if (off[nneigh] > 2000000000ll)
+    return fail(FUS_ERR_LIMIT, "halo exceeds int32 indexing");
+  // concatenated neighbour lists in ascending rank order
+  std::vector<int32_t> pack_idx;
   for (auto& rk : order)
   {
     const int k = rk.second;
+    if (rk.first == op->ctx->rank)
+      return fail(FUS_ERR_ARG, "a rank cannot be its own neighbour");
     Neigh nb;
-    nb.rank = rk.first, nb.count = counts[k];
-    std::vector<int32_t> idx(nb.count);
+    nb.rank = rk.first, nb.count = counts[k], nb.off = (int64_t)pack_idx.size();
     for (int64_t j = 0; j < nb.count; ++j)
-    {
-      const int32_t g = dof_idx[off[k] + j];
-      if (g < 0 || g >= op->ndofs)
-        return fail(FUS_ERR_ARG, "shared dof index out of range");
-      idx[j] = op->L.dof_perm[g];
-      uniq.push_back(idx[j]);
-    }
-    HIPCHK(hipMalloc((void**)&nb.d_idx, std::max<size_t>(1, nb.count) * sizeof(int32_t)));
-    HIPCHK(hipMemcpyAsync(nb.d_idx, idx.data(), nb.count * sizeof(int32_t), hipMemcpyHostToDevice, st));
-    HIPCHK(hipMalloc(&nb.d_send, std::max<size_t>(1, nb.count) * op->ts));
-    HIPCHK(hipMalloc(&nb.d_recv, std::max<size_t>(1, nb.count) * op->ts));
-    HIPCHK(hipStreamSynchronize(st));
+      pack_idx.push_back(op->L.dof_perm[dof_idx[off[k] + j]]);
     op->neigh.push_back(nb);
   }
+  op->n_halo = (int64_t)pack_idx.size();
+  // unique interface dofs and, per dof, its addends in ascending rank order (own = -1)
+  std::vector<int32_t> uniq(pack_idx);
   std::sort(uniq.begin(), uniq.end());
   uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
   op->n_uidx = (int64_t)uniq.size();
-  HIPCHK(hipMalloc((void**)&op->d_uidx, std::max<size_t>(1, uniq.size()) * sizeof(int32_t)));
-  HIPCHK(hipMemcpy(op->d_uidx, uniq.data(), uniq.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc(&op->d_own, std::max<size_t>(1, uniq.size()) * op->ts));
+  std::vector<std::vector<int32_t>> addends(uniq.size());
+  bool own_done_for_rank = false;
+  (void)own_done_for_rank;
+  for (size_t n = 0; n < op->neigh.size(); ++n)
+  {
+    const Neigh& nb = op->neigh[n];
+    // the own partial goes before the first neighbour of higher rank
+    const bool first_higher = nb.rank > op->ctx->rank
+                              && (n == 0 || op->neigh[n - 1].rank < op->ctx->rank);
+    if (first_higher)
+      for (auto& a : addends)
+        a.push_back(-1);
+    for (int64_t j = 0; j < nb.count; ++j)
+    {
+      const size_t u = std::lower_bound(uniq.begin(), uniq.end(), pack_idx[nb.off + j]) - uniq.begin();
+      addends[u].push_back((int32_t)(nb.off + j));
+    }
+  }
+  if (op->neigh.empty() || op->neigh.back().rank < op->ctx->rank)
+    for (auto& a : addends)
+      a.push_back(-1);
+  std::vector<int32_t> uptr(uniq.size() + 1, 0), usrc;
+  for (size_t u = 0; u < uniq.size(); ++u)
+  {
+    // a dof not shared with the lower ranks still has its own partial in rank position: the -1
+    // was appended for every dof at the right place above, so the list is already ordered
+    uptr[u] = (int32_t)usrc.size();
+    usrc.insert(usrc.end(), addends[u].begin(), addends[u].end());
+  }
+  uptr[uniq.size()] = (int32_t)usrc.size();
+  auto up = [&](int32_t** d, const std::vector<int32_t>& v) -> int
+  {
+    HIPCHK(hipMalloc((void**)d, std::max<size_t>(1, v.size()) * sizeof(int32_t)));
+    HIPCHK(hipMemcpy(*d, v.data(), v.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    return FUS_OK;
+  };
+  FUSCHK(up(&op->d_pack_idx, pack_idx));
+  FUSCHK(up(&op->d_uidx, uniq));
+  FUSCHK(up(&op->d_uptr, uptr));
+  FUSCHK(up(&op->d_usrc, usrc));
+  HIPCHK(hipMalloc(&op->d_sendbuf, std::max<size_t>(1, pack_idx.size()) * op->ts));
+  HIPCHK(hipMalloc(&op->d_recvbuf, std::max<size_t>(1, pack_idx.size()) * op->ts));
   return FUS_OK;
 }
 

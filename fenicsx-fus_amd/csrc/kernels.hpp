@@ -935,7 +935,8 @@ __global__ void k_reciprocal(int64_t n, const T* __restrict__ m, T* __restrict__
     minv[i] = (m[i] != T(0)) ? T(1) / m[i] : T(0);
 }
 
-// halo helpers:  buf[k] = vec[idx[k]] ;  vec[idx[k]] = 0 ;  vec[idx[k]] += buf[k]
+// halo helpers
+// pack: sendbuf[k] = vec[idx[k]] over the concatenated neighbour lists
 template <typename T>
 __global__ void k_pack(int64_t n, const int32_t* __restrict__ idx, const T* __restrict__ vec,
                        T* __restrict__ buf)
@@ -944,20 +945,25 @@ __global__ void k_pack(int64_t n, const int32_t* __restrict__ idx, const T* __re
   if (k < n)
     buf[k] = vec[idx[k]];
 }
+// unpack: every sharer adds the partials of an interface dof in ascending rank order (identical
+// bits on all ranks): vec[uidx[j]] = sum_k (src[k] < 0 ? own partial : recvbuf[src[k]])
 template <typename T>
-__global__ void k_zero_at(int64_t n, const int32_t* __restrict__ idx, T* __restrict__ vec)
+__global__ void k_unpack_ordered(int64_t nu, const int32_t* __restrict__ uidx,
+                                 const int32_t* __restrict__ uptr, const int32_t* __restrict__ usrc,
+                                 const T* __restrict__ recvbuf, T* __restrict__ vec)
 {
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n)
-    vec[idx[k]] = T(0);
-}
-template <typename T>
-__global__ void k_add_at(int64_t n, const int32_t* __restrict__ idx, const T* __restrict__ buf,
-                         T* __restrict__ vec)
-{
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k < n)
-    vec[idx[k]] += buf[k];
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nu)
+    return;
+  const int32_t u = uidx[j];
+  const T own = vec[u];
+  T acc = T(0);
+  for (int32_t k = uptr[j]; k < uptr[j + 1]; ++k)
+  {
+    const int32_t sidx = usrc[k];
+    acc += (sidx < 0) ? own : recvbuf[sidx];
+  }
+  vec[u] = acc;
 }
 
 } // namespace fus

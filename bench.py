@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--cells", type=int, default=64, help="cells per axis per GPU")
     ap.add_argument("--P", type=int, default=4)
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--block-elems", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
     ap.add_argument("--deterministic", type=int, default=None, help="1: conflict-free rounds, 0: LDS atomics")
@@ -129,7 +130,8 @@ def main():
         ctx.synchronize()
 
     P, n = args.P, args.cells
-    mesh, V, tags, c0, rho0, freq, p0, dt = workload(n, P, rank, world)
+    np_dtype = np.float64 if args.dtype == "f64" else np.float32
+    mesh, V, tags, c0, rho0, freq, p0, dt = workload(n, P, rank, world, dtype=np_dtype)
     nc = mesh.num_cells
     ndofs_global = V.dofmap.index_map.size_global
 
@@ -175,7 +177,7 @@ def main():
         ctx2.close()
 
     if rank == 0:
-        s = 8
+        s = 8 if args.dtype == "f64" else 4
         N3 = (P + 1) ** 3
         ndl = V.num_dofs
         rho_e = nc * N3 / ndl
@@ -201,7 +203,7 @@ def main():
                 and not args.deterministic and not affine):
             traffic = json.load(open(pmc))["k_block_op_fused"]["hbm_bytes_per_launch"]
         out = {
-            "metric": "DOF-updates/sec (RK4 step) at p=4 hex fp64",
+            "metric": "DOF-updates/sec (RK4 step) at p=4 hex fp64" if (P == 4 and args.dtype == "f64") else f"DOF-updates/sec (RK4 step) at p={P} hex {args.dtype}",
             "value": value,
             "unit": "DOF-updates/s",
             "n_gpus": world,
@@ -211,9 +213,9 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"3D homogeneous wave, {n}^3 hex p={P} fp64 per GPU, Linear RK4 "
+            "config": {"workload": f"3D homogeneous wave, {n}^3 hex p={P} {args.dtype} per GPU, Linear RK4 "
                                    f"(BASELINE.json configs[1])", "ndofs_global": int(ndofs_global),
                        "cells_per_gpu": int(nc), "geometry": "affine (7 fp64 per cell, B_affine)" if affine else "general (G streamed, 6 fp64 per point, B_general)",
                        "partition": f"x-slabs x{world}", "blocks": info["nblocks"],
@@ -237,7 +239,7 @@ def main():
                                      "general (G streamed, B_general)", "value": v2, "unit": "DOF-updates/s",
                                      "ms_per_step": 1e3 * e2 / args.steps, "algorithmic_bytes_per_dof_update": b2,
                                      "frac_of_8TBps": b2 * v2 / world / 8e12, "finite_nonzero_solution": fin2}
-        if not args.no_cpu:
+        if not args.no_cpu and args.dtype == "f64":
             out["cpu_baseline"] = cpu_baseline(P, args.cpu_n, args.cpu_steps)
         print(json.dumps(out))
     if world > 1 or launched:

@@ -1237,7 +1237,9 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
       affine_mesh = false;
   }
   const int be0 = c->block_elems > 0 ? c->block_elems : (affine_mesh ? 16 : 32);
-  const int waves = c->waves > 0 ? c->waves : (affine_mesh ? 2 : 4);
+  int waves = c->waves > 0 ? c->waves : (affine_mesh ? 2 : 4);
+  if (op->P > 4 && waves > 4)
+    waves = 4;  // launch bound of the block kernel for the higher degrees
   // blocks must fit the CU's 160 KB of LDS: halve the block size until they do
   for (int be = be0;; be = (be + 1) / 2)
   {

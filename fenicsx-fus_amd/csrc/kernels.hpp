@@ -337,8 +337,11 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 // :203-221): for the block's interior dofs the sum in LDS is complete, so b never goes to HBM --
 // boundary terms are added in LDS, kv = b * minv, and u_, v_, un', vn' (or the new u0, v0 at stage 3)
 // are written straight from here.  Shared dofs still leave as partial sums.
+// Launch bound: up to 8 waves per workgroup for P <= 4; the higher degrees keep more of the element
+// in registers (beyond 256 per lane) and are limited to 4 waves so one wave per SIMD may use the
+// whole 512-entry register file.
 template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM>
-__global__ void __launch_bounds__(512)
+__global__ void __launch_bounds__((P <= 4) ? 512 : 256)
 k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
            const T* __restrict__ geo, const T* __restrict__ coef, const T* __restrict__ x,
            T* __restrict__ bvec, T* __restrict__ partial, const StageArgs<T> S)

@@ -85,3 +85,18 @@ def test_python_tables_match_oracle(orc):
         po, wo = orc.gll(N)
         assert np.allclose(p, po, atol=1e-15) and np.allclose(w, wo, atol=1e-15)
         assert np.allclose(fa.tables.dphi(p), orc.dphi(po), atol=1e-11)
+
+
+def test_plain_c_consumer_builds_and_runs(tmp_path):
+    """include/fusmi.h is consumable from plain C and the library links without torch/Python:
+    examples/cabi_min.c runs the host-only layout check (and the device path where a GPU exists)."""
+    import subprocess
+
+    exe = tmp_path / "cabi_min"
+    libdir = os.path.join(ROOT, "fenicsx-fus_amd", "fenicsxfus_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "cabi_min.c"), "-L", libdir, "-lfusmi", "-lm",
+                           f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)])
+    out = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "layout ok" in out.stdout

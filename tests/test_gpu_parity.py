@@ -305,3 +305,45 @@ def test_full_size_properties(orc, ctx):
     info = d.info()
     assert d.is_affine() and info["nblocks"] == 262144 // 16 and info["shapes"] == 27   # affine default: 16-element blocks
     d.close()
+
+
+def test_edge_cases_and_errors(orc, ctx):
+    """Single-cell mesh, no boundary facets, bad arguments -> error codes (no exceptions across the ABI)."""
+    import ctypes as C
+
+    from fenicsxfus_amd import _abi
+
+    pr = Problem(orc, (1, 1, 1), 3)
+    d = fa.SpectralOperatorData(pr.V, ctx)
+    x = np.random.default_rng(0).standard_normal(pr.ndofs)
+    assert relmax(d.stiffness(x, np.ones(1), np.zeros(pr.ndofs)), pr.K(x)) < TOL_OP
+    # model without any boundary facet (pure Neumann box): runs, stays zero from zero data
+    empty = fa.FacetTags(np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.int32))
+    mdl = fa.LinearSpectralExplicit(pr.mesh, empty, 3, np.ones(1), np.ones(1), 1.0, 1.0, 1.0, 4, 1e-3, V=pr.V, ctx=ctx)
+    with pytest.raises(fa.FusError, match="init"):
+        mdl.rk(0.0, 1e-2)                      # rk before init -> FUS_ERR_STATE
+    mdl.init()
+    u, v, _ = mdl.rk(0.0, 5e-3)
+    assert mdl.nsteps == 5 and not u.x.array.any()
+    mdl.close()
+    L = _abi.lib()
+    op = C.c_void_p()
+    dm = np.ascontiguousarray(pr.V.tensor_dofmap)
+    xg = np.ascontiguousarray(pr.mesh.geometry.x)
+    gd = np.ascontiguousarray(pr.mesh.geometry.dofmap)
+    nodes = np.ascontiguousarray(pr.V.nodes1d)
+    args = lambda P, dt, order, nd: (ctx.h, 3, P, dt, C.c_int64(1), C.c_int64(pr.ndofs), _abi.ptr(dm), _abi.ptr(nd),  # noqa
+                                     _abi.ptr(xg), C.c_int64(len(xg)), _abi.ptr(gd), order, C.byref(op))
+    assert L.fus_op_create(*args(9, 1, 1, nodes)) == -1 and b"degree" in L.fus_last_error()
+    assert L.fus_op_create(*args(3, 7, 1, nodes)) == -1
+    assert L.fus_op_create(*args(3, 1, 2, nodes)) == -1 and b"geometry" in L.fus_last_error()
+    bad = nodes.copy()
+    bad[1] += 0.01
+    assert L.fus_op_create(*args(3, 1, 1, bad)) == -1 and b"GLL" in L.fus_last_error()
+    with pytest.raises(fa.FusError, match="fields"):      # lossy model on single-field operator data
+        check = _abi.check
+        m = C.c_void_p()
+        one = np.ones(1)
+        check(L.fus_model_create(ctx.h, 1, d.h, _abi.ptr(one), _abi.ptr(one), _abi.ptr(one), None, C.c_int64(0), None,
+                                 None, None, C.c_double(1), C.c_double(1), C.c_double(1), C.byref(m)))
+    d.close()

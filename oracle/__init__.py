@@ -199,3 +199,18 @@ def westervelt_rk4(tdim, N, tensor_dofmap, G, detJ, D, lin_coeff, att_coeff, nli
         a(lin_coeff), a(att_coeff), a(nlin1), a(nlin2), a(m0), a(src), a(absb), a(src2), C.c_double(freq),
         C.c_double(p0), C.c_double(s0), C.c_double(t0), C.c_double(tf), C.c_double(dt), _p(u), _p(v)
     )
+
+
+def linear_rk4_mt(N, tensor_dofmap, G, D, coeff, m, src, absb, freq, p0, s0, t0, tf, dt, u, v, slab_cell_off,
+                  dtype=np.float64, fast=True):
+    """Threaded CPU-baseline variant (3-D): one OpenMP thread per contiguous cell slab."""
+    dm = _arr(tensor_dofmap, np.int32)
+    off = _arr(slab_cell_off, np.int64)
+    fn = getattr(lib(fast), "orc_linear_rk4_mt_" + _suf(dtype))
+    fn.restype = C.c_int64
+    return fn(
+        C.c_int64(dm.shape[0]), C.c_int64(len(u)), C.c_int(N), _p(dm), _p(_arr(G, dtype)), _p(_arr(D, dtype)),
+        _p(_arr(coeff, dtype)), _p(_arr(m, dtype)), _p(_arr(src, dtype)), _p(_arr(absb, dtype)), C.c_double(freq),
+        C.c_double(p0), C.c_double(s0), C.c_double(t0), C.c_double(tf), C.c_double(dt), _p(u), _p(v),
+        C.c_int(len(off) - 1), _p(off)
+    )

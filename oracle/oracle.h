@@ -107,7 +107,15 @@ void orc_dphi(int N, const double* nodes, double* D);
       const REAL* detJ, const REAL* dphi, const REAL* lin_coeff, const REAL* att_coeff,            \
       const REAL* nlin1_coeff, const REAL* nlin2_coeff, const REAL* m0, const REAL* src,           \
       const REAL* absb, const REAL* src2, double freq, double p0, double s0, double t0, double tf, \
-      double dt, REAL* u, REAL* v);
+      double dt, REAL* u, REAL* v);                                                                \
+  /* CPU-baseline variant of orc_linear_rk4 (3-D): nslabs threads, one contiguous cell slab each    \
+   * (slab_cell_off[nslabs+1]); even/odd slab passes replace the interface scatter_rev. */          \
+  int64_t orc_linear_rk4_mt_##SUF(int64_t ncells, int64_t ndofs, int N,                            \
+                                  const int32_t* tensor_dofmap, const REAL* G, const REAL* dphi,   \
+                                  const REAL* coeff, const REAL* m, const REAL* src,               \
+                                  const REAL* absb, double freq, double p0, double s0, double t0,  \
+                                  double tf, double dt, REAL* u, REAL* v, int nslabs,              \
+                                  const int64_t* slab_cell_off);
 
 ORC_DECL(f64, double)
 ORC_DECL(f32, float)

@@ -697,6 +697,92 @@ int64_t FN(orc_westervelt_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
   return step;
 }
 
+
+/* Threaded variant of orc_linear_rk4 for the CPU baseline: the reference runs
+ * one MPI rank per core on an element-wise partition; here the cells (ordered slowest-axis-major, as
+ * BoxMesh emits them) are cut into `nslabs` contiguous slabs, one OpenMP thread per slab with
+ * private scratch.  Slabs of equal parity touch disjoint DOFs, so the operator runs as two
+ * barrier-separated passes (even slabs, odd slabs) -- the role of the interface scatter_rev.  The
+ * vector passes are split statically over the threads.  Same arithmetic per cell as the serial
+ * loop; only the order in which interface-plane contributions are added differs. */
+int64_t FN(orc_linear_rk4_mt)(int64_t ncells, int64_t ndofs, int N, const int32_t* tensor_dofmap,
+                              const REAL* G, const REAL* dphi, const REAL* coeff, const REAL* m,
+                              const REAL* src, const REAL* absb, double freq_, double p0_,
+                              double s0_, double t0, double tf_, double dt_, REAL* u_n, REAL* v_n,
+                              int nslabs, const int64_t* slab_cell_off)
+{
+  const REAL freq = (REAL)freq_, p0 = (REAL)p0_, s0 = (REAL)s0_;
+  const REAL w0 = (REAL)(2 * M_PI * freq_);
+  const REAL period = (REAL)(1.0 / freq_), window_length = (REAL)4.0;
+  const size_t nb = sizeof(REAL) * ndofs;
+  const int Nd = N * N * N;
+  REAL *u_ = (REAL*)malloc(nb), *v_ = (REAL*)malloc(nb), *un = (REAL*)malloc(nb),
+       *vn = (REAL*)malloc(nb), *u0 = (REAL*)malloc(nb), *v0 = (REAL*)malloc(nb),
+       *kv = (REAL*)malloc(nb), *b = (REAL*)malloc(nb);
+  REAL t = (REAL)t0, tf = (REAL)tf_, dt = (REAL)dt_;
+  int64_t step = 0;
+  memcpy(u_, u_n, nb), memcpy(v_, v_n, nb);
+  memcpy(kv, v_, nb);
+  const REAL a_runge[4] = {0.0, 0.5, 0.5, 1.0};
+  const REAL b_runge[4] = {(REAL)(1.0 / 6.0), (REAL)(1.0 / 3.0), (REAL)(1.0 / 3.0),
+                           (REAL)(1.0 / 6.0)};
+  const REAL c_runge[4] = {0.0, 0.5, 0.5, 1.0};
+  while (t < tf)
+  {
+    dt = (dt < tf - t) ? dt : tf - t;
+#pragma omp parallel num_threads(nslabs)
+    {
+#pragma omp for schedule(static)
+      for (int64_t k = 0; k < ndofs; ++k)
+        u0[k] = u_[k], v0[k] = v_[k];
+      for (int i = 0; i < 4; i++)
+      {
+        const REAL adt = dt * a_runge[i], bdt = dt * b_runge[i];
+        const REAL tn = t + c_runge[i] * dt;
+        REAL window;
+        if (tn < period * window_length)
+          window = (REAL)(0.5 * (1.0 - cos((double)(freq * (REAL)M_PI * tn / window_length))));
+        else
+          window = 1.0;
+        const REAL gval = window * p0 * w0 / s0 * (REAL)cos((double)(w0 * tn));
+        /* un = u0 + a dt ku (ku = previous vn), vn = v0 + a dt kv; b = 0  (Linear.hpp:279-283,203) */
+#pragma omp for schedule(static)
+        for (int64_t k = 0; k < ndofs; ++k)
+        {
+          const REAL ku = (i == 0) ? (REAL)0 : vn[k];
+          un[k] = ku * adt + u0[k];
+          vn[k] = kv[k] * adt + v0[k];
+          b[k] = 0;
+        }
+        /* operator: even slabs, then odd slabs */
+        for (int parity = 0; parity < 2; ++parity)
+        {
+#pragma omp for schedule(static, 1)
+          for (int sl = 0; sl < nslabs; ++sl)
+            if ((sl & 1) == parity && slab_cell_off[sl + 1] > slab_cell_off[sl])
+              FN(orc_stiffness3d)(slab_cell_off[sl + 1] - slab_cell_off[sl], N,
+                                  tensor_dofmap + slab_cell_off[sl] * Nd,
+                                  G + slab_cell_off[sl] * Nd * 6, dphi, coeff + slab_cell_off[sl], un, b);
+        }
+        /* boundary terms, divide, accumulate (Linear.hpp:205,212-221,293-294; ku = vn) */
+#pragma omp for schedule(static)
+        for (int64_t k = 0; k < ndofs; ++k)
+        {
+          const REAL bk = b[k] + gval * src[k] - absb[k] * vn[k];
+          kv[k] = bk / m[k];
+          u_[k] = vn[k] * bdt + u_[k];
+          v_[k] = kv[k] * bdt + v_[k];
+        }
+      }
+    }
+    t += dt;
+    step += 1;
+  }
+  memcpy(u_n, u_, nb), memcpy(v_n, v_, nb);
+  free(u_), free(v_), free(un), free(vn), free(u0), free(v0), free(kv), free(b);
+  return step;
+}
+
 #undef FN
 #undef CAT
 #undef CAT_

@@ -170,3 +170,22 @@ def test_lossy_oracle_reduces_to_linear(orc):
     assert np.abs(u1).max() > 0
     assert np.abs(u2 - 2 * u1).max() < 1e-12 * np.abs(u2).max()
     assert keep.any() and src_keep.any()
+
+
+def test_threaded_cpu_baseline_matches_serial(orc):
+    """orc_linear_rk4_mt (bench.py's cpu_baseline leg: one thread per x-slab of cells, even/odd
+    passes) reproduces the serial restatement up to the order of interface additions."""
+    pr = Problem(orc, (8, 3, 3), 3, hi=[0.02, 0.0075, 0.0075], perturb=0.1)
+    tags = tag_box_boundary(pr.mesh)
+    m, src, absb, coeff = pr.linear_model_vectors(1500.0, 1000.0, tags)
+    dt = 0.5 * (0.02 / 8) / (1500.0 * 9)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, 0.5e6, 6e4, 1500.0, 0.0, 8 * dt * (1 - 1e-9), dt, u, v)
+    for nslabs in (1, 3, 8):
+        off = np.linspace(0, 8, nslabs + 1).astype(np.int64) * 9
+        u2, v2 = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+        ns = orc.linear_rk4_mt(pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, 0.5e6, 6e4, 1500.0, 0.0,
+                               8 * dt * (1 - 1e-9), dt, u2, v2, off, fast=False)
+        assert ns == 8 and np.abs(u).max() > 0
+        assert np.abs(u2 - u).max() < 1e-13 * np.abs(u).max()
+        assert np.abs(v2 - v).max() < 1e-13 * np.abs(v).max()

@@ -200,6 +200,7 @@ struct fus_model
   std::vector<void*> allocs;
   bool initialised = false;
   bool setup_done = false;
+  int rk_order = 4;  // explicit Runge-Kutta scheme, tables of python/src/fenicsxfus/_linear.py:286-311
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -861,9 +862,27 @@ template <typename T>
 static StageScalars stage_scalars(const fus_model* m, int i, double t_, double dt_)
 {
   const T t = (T)t_, dt = (T)dt_;
-  const T a_runge[5] = {0.0, 0.5, 0.5, 1.0, 0.0};
-  const T b_runge[4] = {(T)(1.0 / 6.0), (T)(1.0 / 3.0), (T)(1.0 / 3.0), (T)(1.0 / 6.0)};
-  const T c_runge[4] = {0.0, 0.5, 0.5, 1.0};
+  // Runge-Kutta tables (_linear.py:286-311): forward Euler, Ralston 2nd / 3rd order, classical RK4
+  // (Linear.hpp:263-265); a_runge carries one trailing 0 for "the stage after the last"
+  T a_runge[5] = {0.0, 0.5, 0.5, 1.0, 0.0};
+  T b_runge[4] = {(T)(1.0 / 6.0), (T)(1.0 / 3.0), (T)(1.0 / 3.0), (T)(1.0 / 6.0)};
+  T c_runge[4] = {0.0, 0.5, 0.5, 1.0};
+  if (m->rk_order == 1)
+  {
+    a_runge[0] = 0, a_runge[1] = 0, b_runge[0] = 1, c_runge[0] = 0;
+  }
+  else if (m->rk_order == 2)
+  {
+    a_runge[0] = 0, a_runge[1] = (T)(2.0 / 3.0), a_runge[2] = 0;
+    b_runge[0] = (T)(1.0 / 4.0), b_runge[1] = (T)(3.0 / 4.0);
+    c_runge[0] = 0, c_runge[1] = (T)(2.0 / 3.0);
+  }
+  else if (m->rk_order == 3)
+  {
+    a_runge[0] = 0, a_runge[1] = (T)(1.0 / 2.0), a_runge[2] = (T)(3.0 / 4.0), a_runge[3] = 0;
+    b_runge[0] = (T)(2.0 / 9.0), b_runge[1] = (T)(1.0 / 3.0), b_runge[2] = (T)(4.0 / 9.0);
+    c_runge[0] = 0, c_runge[1] = (T)(1.0 / 2.0), c_runge[2] = (T)(3.0 / 4.0);
+  }
   const T freq = (T)m->freq, p0 = (T)m->amp, s0 = (T)m->speed;
   const T w0 = (T)(2 * M_PI * m->freq);
   const T period = (T)(1.0 / m->freq), window_length = (T)4.0;
@@ -893,6 +912,16 @@ static StageScalars stage_scalars(const fus_model* m, int i, double t_, double d
   sc.adt = (double)(dt * a_runge[i + 1]);
   sc.bdt = (double)(dt * b_runge[i]);
   return sc;
+}
+
+// Which fused-update variant stage i uses: 0 = first stage (reads u0, v0 only), 1 = middle stage,
+// 3 = last stage of RK4 (writes the new u0, v0 directly).  The lower-order schemes end on a middle
+// stage and swap (u_, v_) with (u0, v0) afterwards.
+static int stage_kind(const fus_model* m, int i)
+{
+  if (i == 0)
+    return 0;
+  return (m->rk_order == 4 && i == 3) ? 3 : 1;
 }
 
 template <typename T>
@@ -927,18 +956,19 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
   const T* coef = static_cast<const T*>(m->coef);
   {
     ProfScope ps(m->ctx, "stiffness");
+    const int kind = stage_kind(m, i);
     if (m->kind == FUS_LOSSY || m->kind == FUS_WESTERVELT)
     {
-      if (i == 0)
+      if (kind == 0)
         FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 0, 2>(op, G, coef, ustage, b, S)));
-      else if (i == 3)
+      else if (kind == 3)
         FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 3, 2>(op, G, coef, ustage, b, S)));
       else
         FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 1, 2>(op, G, coef, ustage, b, S)));
     }
-    else if (i == 0)
+    else if (kind == 0)
       FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 0>(op, G, coef, ustage, b, S)));
-    else if (i == 3)
+    else if (kind == 3)
       FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 3>(op, G, coef, ustage, b, S)));
     else
       FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 1>(op, G, coef, ustage, b, S)));
@@ -993,7 +1023,7 @@ static int stage_end(fus_model* m, int i, double t, double dt)
   {
     ProfScope ps(c, "stage");
     const dim3 grid(nblk(nloc)), blk(256);
-    switch (i)
+    switch (stage_kind(m, i))
     {
     case 0:
       hipLaunchKernelGGL((k_shared_stage<T, 0>), grid, blk, 0, st, nloc, m->d_sh_ptr32,
@@ -1020,7 +1050,7 @@ static int stage_end(fus_model* m, int i, double t, double dt)
     const int64_t o2 = off + op->L.n_if_start_pad;
     const int64_t n2 = op->L.n_internal - o2;
     const unsigned grid = (unsigned)std::min<int64_t>(nblk(n2 / (16 / sizeof(T))), 256 * 16);
-    switch (i)
+    switch (stage_kind(m, i))
     {
     case 0:
       hipLaunchKernelGGL((k_stage<T, 0>), dim3(grid), dim3(256), 0, st, n2, b + o2, minv + o2,
@@ -1050,7 +1080,7 @@ static int stage_end(fus_model* m, int i, double t, double dt)
 template <typename T, int P>
 static int model_step(fus_model* m, double t, double dt)
 {
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < m->rk_order; ++i)
   {
     FUSCHK((stage_begin<T, P>(m, i, t, dt)));
     if (!m->op->neigh.empty())
@@ -1060,6 +1090,8 @@ static int model_step(fus_model* m, double t, double dt)
     }
     FUSCHK(stage_end<T>(m, i, t, dt));
   }
+  if (m->rk_order != 4)  // the accumulated solution becomes the next step's start state
+    std::swap(m->u_, m->u0), std::swap(m->v_, m->v0);
   return FUS_OK;
 }
 
@@ -1758,7 +1790,7 @@ int fus_group_rk4_steps(fus_model** ms, int n, double t0, double dt, int64_t nst
   double t = t0;
   for (int64_t s = 0; s < nsteps; ++s)
   {
-    for (int st = 0; st < 4; ++st)
+    for (int st = 0; st < ms[0]->rk_order; ++st)
     {
       for (int i = 0; i < n; ++i)
         FUSCHK(d_stage_begin(ms[i], st, t, dt));   // includes the pack
@@ -1769,10 +1801,21 @@ int fus_group_rk4_steps(fus_model** ms, int n, double t0, double dt, int64_t nst
       for (int i = 0; i < n; ++i)
         FUSCHK(d_stage_end(ms[i], st, t, dt));
     }
+    if (ms[0]->rk_order != 4)
+      for (int i = 0; i < n; ++i)
+        std::swap(ms[i]->u_, ms[i]->u0), std::swap(ms[i]->v_, ms[i]->v0);
     t += dt;
   }
   for (int i = 0; i < n; ++i)
     HIPCHK(hipStreamSynchronize(ms[i]->ctx->stream));
+  return FUS_OK;
+}
+
+int fus_model_set_rk_order(fus_model* m, int order)
+{
+  if (!m || order < 1 || order > 4)
+    return fail(FUS_ERR_ARG, "rk order must be 1, 2, 3 or 4");
+  m->rk_order = order;
   return FUS_OK;
 }
 

@@ -3,7 +3,7 @@
 ``LinearSpectralExplicit`` keeps the constructor and ``init()`` / ``rk(t0, tf)`` signatures of
 python/src/fenicsxfus/_linear.py:258-513 (and is the Python face of the C++ ``LinearSpectral3D``,
 cpp/fenicsx-sf/common/Linear.hpp:52-347).  The whole RK4 loop runs on the GPU through
-``fus_model_rk4``; only the classical 4th-order scheme (``rk_order == 4``) is offloaded.
+``fus_model_rk4`` with the reference's Runge-Kutta tables (``rk_order`` 1-4, _linear.py:286-311).
 """
 from __future__ import annotations
 
@@ -23,8 +23,8 @@ class _SpectralExplicit:
     _kind = _abi.FUS_LINEAR
 
     def _create(self, mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt, V, ctx, beta0=None):
-        if rk_order != 4:
-            raise _abi.FusError("only the classical RK4 scheme (rk_order=4) is offloaded")
+        if rk_order not in (1, 2, 3, 4):
+            raise _abi.FusError("rk_order must be 1, 2, 3 or 4 (_linear.py:286-311)")
         self.mesh, self.dt = mesh, dt
         self.freq, self.p0, self.s0 = float(freq0), float(p0), float(s0)
         self.V = V or FunctionSpace(mesh, k)
@@ -43,6 +43,7 @@ class _SpectralExplicit:
                                      ptr(dla), ptr(bta), C.c_int64(len(cells)), ptr(cells), ptr(lf), ptr(tags),
                                      C.c_double(self.freq), C.c_double(self.p0), C.c_double(self.s0),
                                      C.byref(self.h)))
+        check(lib().fus_model_set_rk_order(self.h, C.c_int(rk_order)))
         self.u_n = Function(self.V, dt_)
         self.v_n = Function(self.V, dt_)
 

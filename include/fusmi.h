@@ -155,6 +155,10 @@ int fus_model_create(fus_ctx* ctx, int kind, fus_op* op, const void* c0, const v
                      const int32_t* facet_tags, double freq, double amp, double speed,
                      fus_model** model);
 int fus_model_destroy(fus_model* model);
+/* Explicit Runge-Kutta scheme of the Python reference (python/src/fenicsxfus/_linear.py:286-311):
+ * 1 forward Euler, 2 / 3 Ralston, 4 classical (default; the only one the C++ reference has,
+ * Linear.hpp:263-265).  The entry points named rk4 run the selected scheme. */
+int fus_model_set_rk_order(fus_model* model, int order);
 /* u_n = v_n = 0 (Linear.hpp:161-164). */
 int fus_model_init(fus_model* model);
 /* Classical RK4 from t0 to tf with step dt, `while (t < tf) { dt = min(dt, tf - t); ... }`

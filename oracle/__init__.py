@@ -157,14 +157,15 @@ def facet_diag(tdim, facet_cell, facet_local, cellcoef, xg, xdofmap, pts, wts, t
 
 
 def linear_rk4(tdim, N, tensor_dofmap, G, D, coeff, m, src, absb, freq, p0, s0, t0, tf, dt, u, v,
-               dtype=np.float64, fast=False):
-    """Linear.hpp rk4 restated; u, v updated in place; returns the number of steps taken."""
+               dtype=np.float64, fast=False, order=4):
+    """Linear.hpp rk4 restated (order 1-3: the Python reference's other RK tables); u, v updated in
+    place; returns the number of steps taken."""
     dm = _arr(tensor_dofmap, np.int32)
-    fn = getattr(lib(fast), "orc_linear_rk4_" + _suf(dtype))
+    fn = getattr(lib(fast), "orc_linear_rk_" + _suf(dtype))
     fn.restype = C.c_int64
     assert u.flags.c_contiguous and v.flags.c_contiguous
     return fn(
-        C.c_int(tdim), C.c_int64(dm.shape[0]), C.c_int64(len(u)), C.c_int(N), _p(dm), _p(_arr(G, dtype)),
+        C.c_int(order), C.c_int(tdim), C.c_int64(dm.shape[0]), C.c_int64(len(u)), C.c_int(N), _p(dm), _p(_arr(G, dtype)),
         _p(_arr(D, dtype)), _p(_arr(coeff, dtype)), _p(_arr(m, dtype)), _p(_arr(src, dtype)),
         _p(_arr(absb, dtype)), C.c_double(freq), C.c_double(p0), C.c_double(s0), C.c_double(t0),
         C.c_double(tf), C.c_double(dt), _p(u), _p(v)

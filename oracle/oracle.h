@@ -92,6 +92,12 @@ void orc_dphi(int N, const double* nodes, double* D);
                                const REAL* coeff, const REAL* m, const REAL* src,                  \
                                const REAL* absb, double freq, double p0, double s0, double t0,     \
                                double tf, double dt, REAL* u, REAL* v);                            \
+  /* Same with the explicit RK tables of python/src/fenicsxfus/_linear.py:286-311 (order 1..4). */ \
+  int64_t orc_linear_rk_##SUF(int order, int tdim, int64_t ncells, int64_t ndofs, int N,           \
+                              const int32_t* tensor_dofmap, const REAL* G, const REAL* dphi,       \
+                              const REAL* coeff, const REAL* m, const REAL* src,                   \
+                              const REAL* absb, double freq, double p0, double s0, double t0,      \
+                              double tf, double dt, REAL* u, REAL* v);                             \
   /* Lossy.hpp:176-342 (f1 :196-250): two stiffness actions per stage (u with -1/rho, v with       \
    * -delta/(rho c^2)), heterogeneous source scaling, dg term; see oracle_impl.h. */               \
   int64_t orc_lossy_rk4_##SUF(int tdim, int64_t ncells, int64_t ndofs, int N,                      \

@@ -444,11 +444,13 @@ static void FN(k_axpy)(int64_t n, REAL* r, REAL alpha, const REAL* x, const REAL
 
 /* Linear.hpp:161-314.  Single process: scatter_fwd/scatter_rev (:196,199,206) are no-ops.
  * The FFCx facet assembly (:205) is the diagonal form  b += g(t) src - absb .* v_n. */
-int64_t FN(orc_linear_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
-                           const int32_t* tensor_dofmap, const REAL* G, const REAL* dphi,
-                           const REAL* coeff, const REAL* m, const REAL* src, const REAL* absb,
-                           double freq_, double p0_, double s0_, double t0, double tf_, double dt_,
-                           REAL* u_n, REAL* v_n)
+/* order: 4 = classical RK4 (Linear.hpp:263-265); 1, 2, 3 = forward Euler / Ralston tables of the
+ * Python reference's rk() (python/src/fenicsxfus/_linear.py:286-311, loop :461-499). */
+int64_t FN(orc_linear_rk)(int order, int tdim, int64_t ncells, int64_t ndofs, int N,
+                          const int32_t* tensor_dofmap, const REAL* G, const REAL* dphi,
+                          const REAL* coeff, const REAL* m, const REAL* src, const REAL* absb,
+                          double freq_, double p0_, double s0_, double t0, double tf_, double dt_,
+                          REAL* u_n, REAL* v_n)
 {
   const REAL freq = (REAL)freq_, p0 = (REAL)p0_, s0 = (REAL)s0_;
   const REAL w0 = (REAL)(2 * M_PI * freq_);
@@ -462,15 +464,27 @@ int64_t FN(orc_linear_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
   int64_t step = 0;
   FN(k_copy)(ndofs, u_n, u_), FN(k_copy)(ndofs, v_n, v_);
   FN(k_copy)(ndofs, u_, ku), FN(k_copy)(ndofs, v_, kv);
-  const REAL a_runge[4] = {0.0, 0.5, 0.5, 1.0};
-  const REAL b_runge[4] = {(REAL)(1.0 / 6.0), (REAL)(1.0 / 3.0), (REAL)(1.0 / 3.0),
-                           (REAL)(1.0 / 6.0)};
-  const REAL c_runge[4] = {0.0, 0.5, 0.5, 1.0};
+  REAL a_runge[4] = {0.0, 0.5, 0.5, 1.0};
+  REAL b_runge[4] = {(REAL)(1.0 / 6.0), (REAL)(1.0 / 3.0), (REAL)(1.0 / 3.0), (REAL)(1.0 / 6.0)};
+  REAL c_runge[4] = {0.0, 0.5, 0.5, 1.0};
+  if (order == 1)
+    a_runge[0] = 0, b_runge[0] = 1, c_runge[0] = 0;
+  else if (order == 2)
+  {
+    a_runge[1] = (REAL)(2.0 / 3.0), b_runge[0] = (REAL)(1.0 / 4.0), b_runge[1] = (REAL)(3.0 / 4.0);
+    c_runge[1] = (REAL)(2.0 / 3.0);
+  }
+  else if (order == 3)
+  {
+    a_runge[1] = (REAL)(1.0 / 2.0), a_runge[2] = (REAL)(3.0 / 4.0);
+    b_runge[0] = (REAL)(2.0 / 9.0), b_runge[1] = (REAL)(1.0 / 3.0), b_runge[2] = (REAL)(4.0 / 9.0);
+    c_runge[1] = (REAL)(1.0 / 2.0), c_runge[2] = (REAL)(3.0 / 4.0);
+  }
   while (t < tf)
   {
     dt = (dt < tf - t) ? dt : tf - t;
     FN(k_copy)(ndofs, u_, u0), FN(k_copy)(ndofs, v_, v0);
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < order; i++)
     {
       FN(k_copy)(ndofs, u0, un), FN(k_copy)(ndofs, v0, vn);
       FN(k_axpy)(ndofs, un, dt * a_runge[i], ku, un);
@@ -513,6 +527,16 @@ int64_t FN(orc_linear_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
   return step;
 }
 
+
+int64_t FN(orc_linear_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
+                           const int32_t* tensor_dofmap, const REAL* G, const REAL* dphi,
+                           const REAL* coeff, const REAL* m, const REAL* src, const REAL* absb,
+                           double freq_, double p0_, double s0_, double t0, double tf_, double dt_,
+                           REAL* u_n, REAL* v_n)
+{
+  return FN(orc_linear_rk)(4, tdim, ncells, ndofs, N, tensor_dofmap, G, dphi, coeff, m, src, absb,
+                           freq_, p0_, s0_, t0, tf_, dt_, u_n, v_n);
+}
 
 /* Lossy.hpp:176-342: init + rk4 of the lossy (viscoelastic) model.  f1 (:196-250) applies TWO
  * stiffness actions per stage, lin_op on u_n with -1/rho and att_op on v_n with -delta/(rho c^2)

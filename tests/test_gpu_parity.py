@@ -257,6 +257,27 @@ def test_westervelt_rk4_vs_oracle(orc, ctx):
     model.close(), lm.close()
 
 
+@pytest.mark.parametrize("order", [1, 2, 3])
+def test_lower_rk_orders_vs_oracle(orc, ctx, order):
+    # rk_order 1-3 of LinearSpectralExplicit (_linear.py:286-311): forward Euler, Ralston 2 / 3
+    L = 0.012
+    P, n = 3, (5, 4, 4)
+    pr, c, rho, tags = _linear_setup(orc, ctx, n, P, [L, L, L], perturb=0.1, hetero=True)
+    f0, p0, s0 = 0.5e6, 60000.0, 1500.0
+    dt = 0.1 * (L / n[0]) / (c.max() * P**2)
+    nsteps = 12
+    m, src, absb, coeff = pr.linear_model_vectors(c, rho, tags)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, f0, p0, s0, 0.0, nsteps * dt * (1 - 1e-9), dt, u, v,
+                   order=order)
+    model = fa.LinearSpectralExplicit(pr.mesh, tags, P, c, rho, f0, p0, s0, order, dt, V=pr.V, ctx=ctx)
+    model.init()
+    un, vn, _ = model.rk(0.0, nsteps * dt * (1 - 1e-9))
+    assert model.nsteps == nsteps and np.abs(u).max() > 0
+    assert relmax(un.x.array, u) < TOL_RK and relmax(vn.x.array, v) < TOL_RK
+    model.close()
+
+
 def test_plane_wave_vs_analytical_gpu(orc, ctx):
     # python/tests/test_linearspectral_1d.py:12-107 (degree 4, epw 4): L2 error < 1e-3
     f0, c0, rho0, L, degree, epw = 10.0, 1.0, 4.0, 1.0, 4, 4

@@ -154,7 +154,8 @@ struct fus_op
   Layout L;
   std::vector<double> nodes, wts, D;
   std::vector<char> h_geom_x;        // caller geometry (host copy, T)
-  std::vector<int32_t> h_geom_dm;    // [ncells*8]
+  std::vector<int32_t> h_geom_dm;    // [ncells*geom_nv]
+  int geom_order = 1, geom_nv = 8;   // 1: 8 vertices; 2: 27 nodes in tensor order
   std::vector<int32_t> h_dofmap;     // caller tensor dofmap
   // device
   BlockArgs A{};
@@ -444,10 +445,16 @@ static int ensure_stream_geometry(fus_op* op)
   hipStream_t st = op->ctx->stream;
   FUSCHK(dalloc_bytes(op->allocs, &op->d_G, (size_t)op->ncells * 6 * Nd * sizeof(T), false, st));
   FUSCHK(dalloc_bytes(op->allocs, &op->d_detJ, (size_t)op->ncells * Nd * sizeof(T), false, st));
-  hipLaunchKernelGGL((k_geometry<T, N>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st, op->ncells,
-                     op->d_cell_perm, static_cast<const T*>(op->d_xg), op->d_xdm,
-                     static_cast<const double*>(op->d_pts), static_cast<const double*>(op->d_wts),
-                     static_cast<T*>(op->d_G), static_cast<T*>(op->d_detJ));
+  if (op->geom_order == 1)
+    hipLaunchKernelGGL((k_geometry<T, N, 1>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st,
+                       op->ncells, op->d_cell_perm, static_cast<const T*>(op->d_xg), op->d_xdm,
+                       static_cast<const double*>(op->d_pts), static_cast<const double*>(op->d_wts),
+                       static_cast<T*>(op->d_G), static_cast<T*>(op->d_detJ));
+  else
+    hipLaunchKernelGGL((k_geometry<T, N, 2>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st,
+                       op->ncells, op->d_cell_perm, static_cast<const T*>(op->d_xg), op->d_xdm,
+                       static_cast<const double*>(op->d_pts), static_cast<const double*>(op->d_wts),
+                       static_cast<T*>(op->d_G), static_cast<T*>(op->d_detJ));
   HIPCHK(hipGetLastError());
   return FUS_OK;
 }
@@ -524,14 +531,17 @@ static int op_setup_device(fus_op* op)
   FUSCHK(dalloc(pool, &d_Gc, (size_t)op->ncells * 7));
   FUSCHK(dalloc(pool, &d_err, 1));
   HIPCHK(hipMemsetAsync(d_err, 0, sizeof(unsigned int), st));
-  hipLaunchKernelGGL((k_geometry_affine<T>), dim3(nblk(op->ncells)), dim3(256), 0, st, op->ncells,
-                     op->d_cell_perm, d_xg, op->d_xdm, d_Gc, d_err);
-  HIPCHK(hipGetLastError());
-  unsigned int err_bits = 0;
-  HIPCHK(hipMemcpyAsync(&err_bits, d_err, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
-  HIPCHK(hipStreamSynchronize(st));
-  float rel_err;
-  memcpy(&rel_err, &err_bits, sizeof(float));
+  float rel_err = 1.0f;
+  if (op->geom_order == 1)
+  {
+    hipLaunchKernelGGL((k_geometry_affine<T>), dim3(nblk(op->ncells)), dim3(256), 0, st, op->ncells,
+                       op->d_cell_perm, d_xg, op->d_xdm, d_Gc, d_err);
+    HIPCHK(hipGetLastError());
+    unsigned int err_bits = 0;
+    HIPCHK(hipMemcpyAsync(&err_bits, d_err, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(&rel_err, &err_bits, sizeof(float));
+  }
   op->d_Gc = d_Gc;
   op->affine = c->geometry == 0 && rel_err <= (sizeof(T) == 8 ? 1e-12f : 1e-6f);
   if (op->affine)
@@ -636,17 +646,22 @@ static void facet_diag_host(const fus_op* op, int64_t nfacets, const int32_t* fc
     const int64_t cell = fc[f];
     const int ax = axis3[fl[f]], sd = side3[fl[f]];
     const int d1 = (ax + 1) % 3, d2 = (ax + 2) % 3;
-    T cd[8][3];
-    for (int v = 0; v < 8; ++v)
+    T cd[27][3];
+    const int nv = op->geom_nv;
+    for (int v = 0; v < nv; ++v)
       for (int j = 0; j < 3; ++j)
-        cd[v][j] = xg[3 * (int64_t)op->h_geom_dm[cell * 8 + v] + j];
+        cd[v][j] = xg[3 * (int64_t)op->h_geom_dm[cell * nv + v] + j];
     for (int a = 0; a < N; ++a)
       for (int b = 0; b < N; ++b)
       {
         int idx[3];
         idx[ax] = sd ? i_hi : i_lo, idx[d1] = a, idx[d2] = b;
         T J[3][3];
-        jacobian3<T>(cd, op->nodes[idx[0]], op->nodes[idx[1]], op->nodes[idx[2]], J);
+        if (op->geom_order == 1)
+          jacobian3<T>(reinterpret_cast<const T(*)[3]>(cd), op->nodes[idx[0]], op->nodes[idx[1]],
+                       op->nodes[idx[2]], J);
+        else
+          jacobian3_q2<T>(cd, op->nodes[idx[0]], op->nodes[idx[1]], op->nodes[idx[2]], J);
         const T t1[3] = {J[0][d1], J[1][d1], J[2][d1]}, t2[3] = {J[0][d2], J[1][d2], J[2][d2]};
         const T n0 = t1[1] * t2[2] - t1[2] * t2[1], n1 = t1[2] * t2[0] - t1[0] * t2[2],
                 n2 = t1[0] * t2[1] - t1[1] * t2[0];
@@ -1233,18 +1248,19 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   op->allocs.clear();
   // centroids for the block partitioner
   std::vector<double> cen((size_t)op->ncells * 3, 0.0);
+  const int nv = op->geom_nv;
   for (int64_t cidx = 0; cidx < op->ncells; ++cidx)
-    for (int v = 0; v < 8; ++v)
+    for (int v = 0; v < nv; ++v)
       for (int j = 0; j < 3; ++j)
       {
-        const size_t k = 3 * (size_t)op->h_geom_dm[cidx * 8 + v] + j;
+        const size_t k = 3 * (size_t)op->h_geom_dm[cidx * nv + v] + j;
         cen[3 * cidx + j] +=
-            0.125 * (op->dtype == FUS_F64 ? reinterpret_cast<const double*>(op->h_geom_x.data())[k]
+            (1.0 / nv) * (op->dtype == FUS_F64 ? reinterpret_cast<const double*>(op->h_geom_x.data())[k]
                                           : (double)reinterpret_cast<const float*>(op->h_geom_x.data())[k]);
       }
   // will the per-cell (affine) geometry path be taken?  (same test as k_geometry_affine, on the host
   // copy: every vertex of every cell on the parallelepiped spanned by vertices 0, 1, 2, 4)
-  bool affine_mesh = c->geometry == 0;
+  bool affine_mesh = c->geometry == 0 && op->geom_order == 1;
   for (int64_t cidx = 0; cidx < op->ncells && affine_mesh; ++cidx)
   {
     double cd[8][3], h2 = 0, e2 = 0;
@@ -1463,8 +1479,8 @@ int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_
     return fail(FUS_ERR_ARG, "unsupported polynomial degree (2..7)");
   if (dtype != FUS_F64 && dtype != FUS_F32)
     return fail(FUS_ERR_ARG, "dtype must be FUS_F32 or FUS_F64");
-  if (geom_order != 1)
-    return fail(FUS_ERR_ARG, "only first-order (trilinear) geometry is supported");
+  if (geom_order != 1 && geom_order != 2)
+    return fail(FUS_ERR_ARG, "geometry order must be 1 (8 vertices) or 2 (27 nodes, tensor order)");
   if (ncells <= 0 || ndofs <= 0 || nnodes <= 0)
     return fail(FUS_ERR_ARG, "empty mesh");
   const int N = P + 1;
@@ -1482,9 +1498,10 @@ int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_
   op->D = dphi_table(N, nodes1d);
   op->h_geom_x.assign(static_cast<const char*>(geom_x),
                       static_cast<const char*>(geom_x) + (size_t)nnodes * 3 * op->ts);
-  op->h_geom_dm.assign(geom_dofmap, geom_dofmap + ncells * 8);
+  op->geom_order = geom_order, op->geom_nv = geom_order == 1 ? 8 : 27;
+  op->h_geom_dm.assign(geom_dofmap, geom_dofmap + ncells * op->geom_nv);
   op->h_dofmap.assign(tensor_dofmap, tensor_dofmap + ncells * op->Nd);
-  for (int64_t k = 0; k < ncells * 8; ++k)
+  for (int64_t k = 0; k < ncells * op->geom_nv; ++k)
     if (geom_dofmap[k] < 0 || geom_dofmap[k] >= nnodes)
       return fail(FUS_ERR_ARG, "geometry dofmap entry out of range");
   int r = op_build(op.get(), nullptr);

@@ -38,6 +38,38 @@ FUS_HD inline void jacobian3(const T cd[8][3], double X0, double X1, double X2, 
   }
 }
 
+// Second-order (27-node, triquadratic) hexahedron: nodes in TENSOR order n = nx + 3 ny + 9 nz with
+// n_d in {0,1,2} <-> reference coordinate {0, 1/2, 1}; phi_n = l_nx(X0) l_ny(X1) l_nz(X2), the 1-D
+// quadratic Lagrange basis.  (DOLFINx stores these nodes vertices-edges-faces-interior; the adapter
+// permutes.)  precompute.hpp:52-55 tabulates the coordinate element of whatever order the mesh has.
+template <typename T>
+FUS_HD inline void jacobian3_q2(const T cd[27][3], double X0, double X1, double X2, T J[3][3])
+{
+  const double X[3] = {X0, X1, X2};
+  T l[3][3], dl[3][3];
+  for (int d = 0; d < 3; ++d)
+  {
+    const double x = X[d];
+    l[d][0] = (T)((2.0 * x - 1.0) * (x - 1.0)), dl[d][0] = (T)(4.0 * x - 3.0);
+    l[d][1] = (T)(4.0 * x * (1.0 - x)), dl[d][1] = (T)(4.0 - 8.0 * x);
+    l[d][2] = (T)(x * (2.0 * x - 1.0)), dl[d][2] = (T)(4.0 * x - 1.0);
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      J[i][j] = 0;
+  for (int nz = 0; nz < 3; ++nz)
+    for (int ny = 0; ny < 3; ++ny)
+      for (int nx = 0; nx < 3; ++nx)
+      {
+        const int n = nx + 3 * ny + 9 * nz;
+        const T g[3] = {dl[0][nx] * l[1][ny] * l[2][nz], l[0][nx] * dl[1][ny] * l[2][nz],
+                        l[0][nx] * l[1][ny] * dl[2][nz]};
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j)
+            J[i][j] += cd[n][i] * g[j];
+      }
+}
+
 // G6 = (xx, xy, xz, yy, yz, zz) of K K^T |det J| w; returns |det J| w  (precompute.hpp:191-208)
 template <typename T>
 FUS_HD inline T geometric_factor3(const T J[3][3], T w, T G6[6])

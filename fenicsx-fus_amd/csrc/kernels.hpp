@@ -791,14 +791,16 @@ k_stage(int64_t n, const T* __restrict__ b, const T* __restrict__ minv, T* __res
 // ---------------------------------------------------------------------------------------------
 
 // Geometry factors for internal element e at point q (precompute.hpp:101-213, 33-94), written in
-// the operator's streaming layouts.
-template <typename T, int N>
+// the operator's streaming layouts.  GORD = geometry order: 1 (8 vertices) or 2 (27 nodes, tensor
+// order).
+template <typename T, int N, int GORD>
 __global__ void k_geometry(int64_t ncells, const int32_t* __restrict__ cell_perm,
                            const T* __restrict__ xg, const int32_t* __restrict__ xdofmap,
                            const double* __restrict__ pts, const double* __restrict__ wts,
                            T* __restrict__ G, T* __restrict__ detJ)
 {
   constexpr int N2 = N * N, Nd = N * N * N;
+  constexpr int NVG = (GORD == 1) ? 8 : 27;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= ncells * Nd)
     return;
@@ -806,12 +808,15 @@ __global__ void k_geometry(int64_t ncells, const int32_t* __restrict__ cell_perm
   const int q = (int)(gid - e * Nd);
   const int a = q / N2, p = q - a * N2, bb = p / N, cc = p - bb * N;
   const int64_t cell = cell_perm[e];
-  T cd[8][3];
-  for (int v = 0; v < 8; ++v)
+  T cd[NVG][3];
+  for (int v = 0; v < NVG; ++v)
     for (int j = 0; j < 3; ++j)
-      cd[v][j] = xg[3 * (int64_t)xdofmap[cell * 8 + v] + j];
+      cd[v][j] = xg[3 * (int64_t)xdofmap[cell * NVG + v] + j];
   T J[3][3], G6[6];
-  jacobian3<T>(cd, pts[a], pts[bb], pts[cc], J);
+  if constexpr (GORD == 1)
+    jacobian3<T>(cd, pts[a], pts[bb], pts[cc], J);
+  else
+    jacobian3_q2<T>(cd, pts[a], pts[bb], pts[cc], J);
   const T w = (T)(wts[a] * wts[bb] * wts[cc]);
   const T dw = geometric_factor3<T>(J, w, G6);
   detJ[e * Nd + q] = dw;

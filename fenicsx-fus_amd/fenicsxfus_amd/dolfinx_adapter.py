@@ -117,3 +117,37 @@ def wrap_facet_tags(mesh, meshtags):
     from .mesh import FacetTags
 
     return FacetTags(np.concatenate(cells), np.concatenate(lfs), np.concatenate(vals))
+
+
+# Second-order (27-node) hexahedron: DOLFINx/Basix store geometry nodes as vertices, edges, faces,
+# interior, following the reference-cell topology (vertex v = vx + 2 vy + 4 vz; edges and faces in
+# lexicographic vertex order).  libfusmi takes them in tensor order n = nx + 3 ny + 9 nz.
+# NOT verifiable here (no Basix): check `perm` against `basix.geometry/topology(CellType.hexahedron)`
+# where DOLFINx exists before relying on it.
+_HEX_EDGES = [(0, 1), (0, 2), (0, 4), (1, 3), (1, 5), (2, 3), (2, 6), (3, 7), (4, 5), (4, 6), (5, 7), (6, 7)]
+_HEX_FACES = [(0, 1, 2, 3), (0, 1, 4, 5), (0, 2, 4, 6), (1, 3, 5, 7), (2, 3, 6, 7), (4, 5, 6, 7)]
+
+
+def hex27_dolfinx_to_tensor():
+    """perm with tensor_nodes[:, perm[k]] = dolfinx_nodes[:, k]: position (in tensor order) of the
+    k-th DOLFINx geometry node of a second-order hexahedron."""
+    def pos(v):
+        return np.array([v & 1, (v >> 1) & 1, v >> 2]) * 2
+    nodes = [pos(v) for v in range(8)]
+    nodes += [(pos(a) + pos(b)) // 2 for a, b in _HEX_EDGES]
+    nodes += [sum(pos(v) for v in f) // 4 for f in _HEX_FACES]
+    nodes.append(np.array([1, 1, 1]))
+    return np.array([n[0] + 3 * n[1] + 9 * n[2] for n in nodes], dtype=np.int64)
+
+
+def tensor_geometry_dofmap(mesh):
+    """Geometry dofmap of a DOLFINx mesh in the order libfusmi expects (order 1: unchanged)."""
+    gd = np.asarray(mesh.geometry.dofmap)
+    if gd.shape[1] == 8:
+        return gd.astype(np.int32)
+    if gd.shape[1] != 27:
+        raise ValueError("only first- and second-order hexahedral geometry is supported")
+    perm = hex27_dolfinx_to_tensor()
+    out = np.empty_like(gd, dtype=np.int32)
+    out[:, perm] = gd
+    return out

@@ -50,9 +50,17 @@ class BoxMesh:
     """
 
     def __init__(self, lo, hi, n, rank: int = 0, size: int = 1, dtype=np.float64, perturb: float = 0.0,
-                 seed: int = 0):
+                 seed: int = 0, order: int = 1, warp=None):
         self.tdim = len(n)
         assert self.tdim in (2, 3)
+        self.order = order
+        if order == 2:
+            # second-order (27-node) hexahedra, geometry nodes in tensor order n = nx + 3 ny + 9 nz;
+            # ``warp(x) -> x'`` (x: [nnodes, 3]) bends the node lattice (curved cells)
+            assert self.tdim == 3 and not perturb
+            self._init_second_order(lo, hi, n, rank, size, dtype, warp)
+            return
+        assert warp is None
         self.n = tuple(int(k) for k in n)
         self.lo = np.asarray(lo, dtype=np.float64)
         self.hi = np.asarray(hi, dtype=np.float64)
@@ -98,6 +106,34 @@ class BoxMesh:
         self.geometry = _Geometry(x.astype(self.dtype), dm, self.tdim)
         ncg = int(np.prod(self.n))
         self.topology = _Topology(self.tdim, dm.shape[0], ncg)
+        self._cidx = cidx
+
+    def _init_second_order(self, lo, hi, n, rank, size, dtype, warp):
+        self.n = tuple(int(k) for k in n)
+        self.lo, self.hi = np.asarray(lo, dtype=np.float64), np.asarray(hi, dtype=np.float64)
+        self.rank, self.size, self.dtype = rank, size, np.dtype(dtype)
+        nx = self.n[0]
+        self.cx0, self.cx1 = (nx * rank) // size, (nx * (rank + 1)) // size
+        self.nloc = (self.cx1 - self.cx0,) + self.n[1:]
+        nn = [2 * k + 1 for k in self.nloc]                     # node lattice, half-cell spacing
+        axes = []
+        for d in range(3):
+            h = (self.hi[d] - self.lo[d]) / self.n[d]
+            off = self.cx0 if d == 0 else 0
+            axes.append(self.lo[d] + 0.5 * h * (2 * off + np.arange(nn[d])))
+        grid = np.meshgrid(*axes, indexing="ij")
+        x = np.stack([g.ravel() for g in grid], axis=1)
+        if warp is not None:
+            x = np.asarray(warp(x), dtype=np.float64)
+        cidx = np.indices(self.nloc).reshape(3, -1)
+        dm = np.empty((cidx.shape[1], 27), dtype=np.int32)
+        for nz in range(3):
+            for ny in range(3):
+                for nxx in range(3):
+                    nid = ((2 * cidx[0] + nxx) * nn[1] + 2 * cidx[1] + ny) * nn[2] + 2 * cidx[2] + nz
+                    dm[:, nxx + 3 * ny + 9 * nz] = nid
+        self.geometry = _Geometry(x.astype(self.dtype), dm, 3)
+        self.topology = _Topology(3, dm.shape[0], int(np.prod(self.n)))
         self._cidx = cidx
 
     def _global_vertex_ids(self, nvert):

@@ -87,8 +87,11 @@ int fus_comm_init_local(fus_ctx** ctxs, int n);
  *   dtype       FUS_F64 | FUS_F32: type of geom_x and of every vector/coefficient argument later
  *   tensor_dofmap  int32[ncells * N^3], local DOF indices < ndofs, x-slowest tensor order
  *   nodes1d     double[N]
- *   geom_x      T[nnodes * 3]; geom_dofmap int32[ncells * 8], vertex order v = vx + 2vy + 4vz
- *   geom_order  1 (trilinear).  Higher-order geometry -> FUS_ERR_ARG.
+ *   geom_x      T[nnodes * 3]
+ *   geom_order  1: geom_dofmap int32[ncells * 8], vertex order v = vx + 2vy + 4vz (DOLFINx's);
+ *               2: geom_dofmap int32[ncells * 27], nodes in tensor order n = nx + 3ny + 9nz with
+ *                  n_d in {0,1,2} <-> reference coordinate {0, 1/2, 1} (the caller permutes from
+ *                  DOLFINx's vertices-edges-faces-interior order).  Other orders -> FUS_ERR_ARG.
  * All arrays are caller-owned host memory, copied during the call. */
 int fus_op_create(fus_ctx* ctx, int tdim, int P, int dtype, int64_t ncells, int64_t ndofs,
                   const int32_t* tensor_dofmap, const double* nodes1d, const void* geom_x,

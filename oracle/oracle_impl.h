@@ -179,6 +179,123 @@ void FN(orc_geometry)(int tdim, int64_t ncells, const REAL* xg, const int32_t* x
   }
 }
 
+
+/* ---- second-order (27-node) hexahedral geometry ---------------------------------------------------
+ * precompute.hpp:52-55 tabulates the mesh's coordinate element whatever its degree; for degree 2
+ * (the reference's Gmsh `mesh_2` fixtures, cpp/fenicsx-sf-naive/tests/test_operators3d) the map is
+ * triquadratic.  Nodes in tensor order n = nx + 3 ny + 9 nz, n_d in {0,1,2} <-> X_d in {0,1/2,1}. */
+static void FN(jac3_q2)(const REAL cd[27][3], double X0, double X1, double X2, REAL J[3][3])
+{
+  const double X[3] = {X0, X1, X2};
+  REAL l[3][3], dl[3][3];
+  for (int d = 0; d < 3; ++d)
+  {
+    const double x = X[d];
+    l[d][0] = (REAL)((2.0 * x - 1.0) * (x - 1.0)), dl[d][0] = (REAL)(4.0 * x - 3.0);
+    l[d][1] = (REAL)(4.0 * x * (1.0 - x)), dl[d][1] = (REAL)(4.0 - 8.0 * x);
+    l[d][2] = (REAL)(x * (2.0 * x - 1.0)), dl[d][2] = (REAL)(4.0 * x - 1.0);
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      J[i][j] = 0;
+  for (int nz = 0; nz < 3; ++nz)
+    for (int ny = 0; ny < 3; ++ny)
+      for (int nx = 0; nx < 3; ++nx)
+      {
+        const int n = nx + 3 * ny + 9 * nz;
+        const REAL g[3] = {dl[0][nx] * l[1][ny] * l[2][nz], l[0][nx] * dl[1][ny] * l[2][nz],
+                           l[0][nx] * l[1][ny] * dl[2][nz]};
+        for (int i = 0; i < 3; ++i)
+          for (int j = 0; j < 3; ++j)
+            J[i][j] += cd[n][i] * g[j];
+      }
+}
+
+void FN(orc_geometry_q2)(int64_t ncells, const REAL* xg, const int32_t* xdofmap, int N,
+                         const double* pts, const double* wts, REAL* G, REAL* detJ)
+{
+  const int Nd = N * N * N;
+  for (int64_t c = 0; c < ncells; ++c)
+  {
+    REAL cd[27][3];
+    for (int v = 0; v < 27; ++v)
+      for (int j = 0; j < 3; ++j)
+        cd[v][j] = xg[3 * (int64_t)xdofmap[c * 27 + v] + j];
+    for (int q0 = 0; q0 < N; ++q0)
+      for (int q1 = 0; q1 < N; ++q1)
+        for (int q2 = 0; q2 < N; ++q2)
+        {
+          const int q = (q0 * N + q1) * N + q2;
+          const REAL w = (REAL)(wts[q0] * wts[q1] * wts[q2]);
+          REAL J[3][3], K[3][3];
+          FN(jac3_q2)(cd, pts[q0], pts[q1], pts[q2], J);
+          const REAL c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+          const REAL c01 = J[1][2] * J[2][0] - J[1][0] * J[2][2];
+          const REAL c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+          const REAL det = J[0][0] * c00 + J[0][1] * c01 + J[0][2] * c02;
+          K[0][0] = c00 / det, K[1][0] = c01 / det, K[2][0] = c02 / det;
+          K[0][1] = (J[0][2] * J[2][1] - J[0][1] * J[2][2]) / det;
+          K[1][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+          K[2][1] = (J[0][1] * J[2][0] - J[0][0] * J[2][1]) / det;
+          K[0][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+          K[1][2] = (J[0][2] * J[1][0] - J[0][0] * J[1][2]) / det;
+          K[2][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+          const REAL dw = (REAL)fabs((double)det) * w;
+          if (detJ)
+            detJ[c * Nd + q] = dw;
+          if (G)
+          {
+            REAL* g = G + (c * Nd + q) * 6;
+            int n = 0;
+            for (int i = 0; i < 3; ++i)
+              for (int j = i; j < 3; ++j)
+                g[n++] = dw * (K[i][0] * K[j][0] + K[i][1] * K[j][1] + K[i][2] * K[j][2]);
+          }
+        }
+  }
+}
+
+void FN(orc_facet_diag_q2)(int64_t nfacets, const int32_t* facet_cell, const int32_t* facet_local,
+                           const REAL* cellcoef, const REAL* xg, const int32_t* xdofmap, int N,
+                           const double* pts, const double* wts, const int32_t* tensor_dofmap,
+                           REAL* out)
+{
+  static const int axis3[6] = {2, 1, 0, 0, 1, 2}, side3[6] = {0, 0, 0, 1, 1, 1};
+  const int Nd = N * N * N;
+  int i_lo = 0, i_hi = 0;
+  for (int i = 0; i < N; ++i)
+  {
+    if (pts[i] < pts[i_lo])
+      i_lo = i;
+    if (pts[i] > pts[i_hi])
+      i_hi = i;
+  }
+  for (int64_t f = 0; f < nfacets; ++f)
+  {
+    const int64_t c = facet_cell[f];
+    const int ax = axis3[facet_local[f]], sd = side3[facet_local[f]];
+    const int d1 = (ax + 1) % 3, d2 = (ax + 2) % 3;
+    REAL cd[27][3];
+    for (int v = 0; v < 27; ++v)
+      for (int j = 0; j < 3; ++j)
+        cd[v][j] = xg[3 * (int64_t)xdofmap[c * 27 + v] + j];
+    for (int a = 0; a < N; ++a)
+      for (int b = 0; b < N; ++b)
+      {
+        int idx[3];
+        idx[ax] = sd ? i_hi : i_lo, idx[d1] = a, idx[d2] = b;
+        REAL J[3][3];
+        FN(jac3_q2)(cd, pts[idx[0]], pts[idx[1]], pts[idx[2]], J);
+        const REAL t1[3] = {J[0][d1], J[1][d1], J[2][d1]}, t2[3] = {J[0][d2], J[1][d2], J[2][d2]};
+        const REAL n0 = t1[1] * t2[2] - t1[2] * t2[1], n1 = t1[2] * t2[0] - t1[0] * t2[2],
+                   n2 = t1[0] * t2[1] - t1[1] * t2[0];
+        const REAL area = (REAL)sqrt((double)(n0 * n0 + n1 * n1 + n2 * n2));
+        const int li = (idx[0] * N + idx[1]) * N + idx[2];
+        out[tensor_dofmap[c * Nd + li]] += cellcoef[c] * area * (REAL)(wts[a] * wts[b]);
+      }
+  }
+}
+
 /* spectral_op.hpp:69-86 with mass::transform :19-26 (identical in the naive 2-D class) */
 void FN(orc_mass)(int tdim, int64_t ncells, int N, const int32_t* tensor_dofmap, const REAL* detJ,
                   const REAL* coeffs, const REAL* x, REAL* y)

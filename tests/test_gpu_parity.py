@@ -368,3 +368,34 @@ def test_edge_cases_and_errors(orc, ctx):
         check(L.fus_model_create(ctx.h, 1, d.h, _abi.ptr(one), _abi.ptr(one), _abi.ptr(one), None, C.c_int64(0), None,
                                  None, None, C.c_double(1), C.c_double(1), C.c_double(1), C.byref(m)))
     d.close()
+
+
+def test_second_order_geometry_gpu(orc, ctx):
+    """Curved 27-node hexahedra: geometry factors, operators and a short RK4 run against the oracle."""
+    from test_oracle_operators import _bend
+
+    pr = Problem(orc, (4, 3, 3), 4, hi=[0.016, 0.012, 0.012], order=2,
+                 warp=lambda x: x + np.c_[20.0 * x[:, 1] ** 2 - 12.0 * x[:, 2] ** 2, 15.0 * x[:, 2] ** 2, 0 * x[:, 0]])
+    d = fa.SpectralOperatorData(pr.V, ctx)
+    assert not d.is_affine()
+    G, dJ = d.geometry()
+    assert relmax(G, pr.G) < 1e-13 and relmax(dJ, pr.detJ) < 1e-13
+    rng = np.random.default_rng(5)
+    x, coef = rng.standard_normal(pr.ndofs), rng.uniform(0.5, 2.0, pr.mesh.num_cells)
+    assert relmax(d.stiffness(x, coef, np.zeros(pr.ndofs)), pr.K(x, coef)) < TOL_OP
+    assert relmax(d.mass(x, coef, np.zeros(pr.ndofs)), pr.M(x, coef)) < 1e-14
+    d.close()
+    nc = pr.mesh.num_cells
+    c, rho = np.full(nc, 1500.0), np.full(nc, 1000.0)
+    tags = tag_box_boundary(pr.mesh)
+    m, src, absb, coeff = pr.linear_model_vectors(c, rho, tags)
+    dt = 0.3 * 0.004 / (1500.0 * 16)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, 0.5e6, 6e4, 1500.0, 0.0, 10 * dt * (1 - 1e-9), dt, u, v)
+    model = fa.LinearSpectralExplicit(pr.mesh, tags, 4, c, rho, 0.5e6, 6e4, 1500.0, 4, dt, V=pr.V, ctx=ctx)
+    assert relmax(model.mass_vector(), m) < 1e-14
+    model.init()
+    un, vn, _ = model.rk(0.0, 10 * dt * (1 - 1e-9))
+    assert np.abs(u).max() > 0 and relmax(un.x.array, u) < TOL_RK and relmax(vn.x.array, v) < TOL_RK
+    model.close()
+    assert _bend is not None

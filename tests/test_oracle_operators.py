@@ -189,3 +189,42 @@ def test_threaded_cpu_baseline_matches_serial(orc):
         assert ns == 8 and np.abs(u).max() > 0
         assert np.abs(u2 - u).max() < 1e-13 * np.abs(u).max()
         assert np.abs(v2 - v).max() < 1e-13 * np.abs(v).max()
+
+
+def _bend(x):
+    """Volume-preserving quadratic map (det = 1): triquadratic cells represent it exactly."""
+    y = x.copy()
+    y[:, 0] += 0.3 * x[:, 1] ** 2 - 0.2 * x[:, 2] ** 2
+    y[:, 1] += 0.25 * x[:, 2] ** 2
+    return y
+
+
+def test_second_order_geometry(orc):
+    """27-node hexahedra (tensor node order): straight cells reproduce the trilinear factors; on
+    curved cells the operator keeps K 1 = 0, symmetry, agreement with the dense-table evaluation,
+    exact volume (det of the bend = 1) and exact energy of a physically linear field."""
+    L = [1.2, 1.0, 0.8]
+    a = Problem(orc, (3, 2, 2), 4, hi=L)
+    b = Problem(orc, (3, 2, 2), 4, hi=L, order=2)
+    assert b.mesh.geometry.dofmap.shape[1] == 27
+    assert np.abs(a.G - b.G).max() < 1e-13 * np.abs(a.G).max()
+    assert np.abs(a.detJ - b.detJ).max() < 1e-13 * np.abs(a.detJ).max()
+    c = Problem(orc, (3, 2, 2), 4, hi=L, order=2, warp=_bend)
+    assert np.abs(c.G - a.G).max() > 1e-3 * np.abs(a.G).max()          # really curved
+    rng = np.random.default_rng(0)
+    x, z = rng.standard_normal(c.ndofs), rng.standard_normal(c.ndofs)
+    y = c.K(x)
+    assert np.abs(c.K(np.ones(c.ndofs))).max() < 1e-12 * np.abs(y).max()
+    assert abs(z @ y - x @ c.K(z)) < 1e-11 * abs(z @ y)
+    assert np.abs(y - c.K(x, dense=True)).max() < 1e-12 * np.abs(y).max()
+    assert abs(c.M(np.ones(c.ndofs)).sum() - np.prod(L)) < 1e-13 * np.prod(L)
+    Xp = _bend(c.V.tabulate_dof_coordinates())                           # physical dof coordinates
+    u = Xp[:, 0].copy()                                                  # grad u = e_x everywhere
+    assert abs(u @ c.K(u) - np.prod(L)) < 1e-12 * np.prod(L)
+    # boundary weights: area of the bent x = 0 face, tangents (0.6y, 1, 0) and (-0.4z, 0.5z, 1)
+    tags = tag_box_boundary(c.mesh)
+    area_src = c.facet_diag(tags, 1, np.ones(c.mesh.num_cells)).sum()
+    yy, zz = np.meshgrid(np.linspace(0, L[1], 2001), np.linspace(0, L[2], 2001), indexing="ij")
+    dA = np.sqrt(1 + (0.6 * yy) ** 2 + (0.3 * yy * zz + 0.4 * zz) ** 2)  # |d(x')/dy x d(x')/dz| on x = 0
+    ref = np.trapezoid(np.trapezoid(dA, zz[0], axis=1), yy[:, 0])
+    assert abs(area_src - ref) < 1e-5 * ref      # GLL quadrature of a smooth non-polynomial integrand

@@ -8,11 +8,11 @@ class Problem:
     """Everything the oracle needs for one mesh: tables, geometry factors, dofmap."""
 
     def __init__(self, orc, n, P, lo=None, hi=None, perturb=0.0, node_order=None, dtype=np.float64,
-                 rank=0, size=1):
+                 rank=0, size=1, order=1, warp=None):
         t = len(n)
         lo = [0.0] * t if lo is None else lo
         hi = [1.0] * t if hi is None else hi
-        self.mesh = BoxMesh(lo, hi, n, perturb=perturb, dtype=dtype, rank=rank, size=size)
+        self.mesh = BoxMesh(lo, hi, n, perturb=perturb, dtype=dtype, rank=rank, size=size, order=order, warp=warp)
         self.V = FunctionSpace(self.mesh, P, node_order=node_order)
         self.P, self.N, self.tdim, self.dtype = P, P + 1, t, np.dtype(dtype)
         self.nodes = self.V.nodes1d

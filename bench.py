@@ -231,11 +231,13 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {"workload": f"3D homogeneous wave, {n}^3 hex p={P} {args.dtype} per GPU, Linear RK4 "
-                                   f"(BASELINE.json configs[1])", "ndofs_global": int(ndofs_global),
+                                   + ("(BASELINE.json configs[1])" if (n, P, args.dtype) == (64, 4, "f64") else
+                                     "(BASELINE.json configs[2])" if (n, P, args.dtype) == (128, 7, "f64") else
+                                     "(parity/diagnostic configuration)"), "ndofs_global": int(ndofs_global),
                        "cells_per_gpu": int(nc), "geometry": "affine (7 fp64 per cell, B_affine)" if affine else "general (G streamed, 6 fp64 per point, B_general)",
                        "partition": f"x-slabs x{world}", "blocks": info["nblocks"],
                        "lds_bytes_per_block": info["lds_bytes"], "dt": dt},
-            "roofline": {"bound": "hbm", "kernel": "k_block_op<double,4,stiffness,+fused RK4 stage>", "achieved": achieved,
+            "roofline": {"bound": "hbm", "kernel": f"k_block_op<{'double' if args.dtype == 'f64' else 'float'},{P},stiffness,+fused RK4 stage>", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
                          "traffic_source": "profiles/r01c_pmc_traffic.json (separate rocprofv3 --pmc passes)",
                          "algorithmic_bytes_per_launch": alg_launch, "interior_dofs": n_int, "avg_launch_ms": avg_ms,

@@ -128,7 +128,7 @@ struct fus_ctx
   int deterministic = 0;  // 1: conflict-free rounds (bitwise reproducible); 0: LDS atomics
   int fields = 1;         // operator inputs per block pass the ops are sized for (2: Lossy)
   int geometry = 0;       // 0: auto (per-cell factors when every cell is affine), 1: always stream G
-  // 0 = auto: 32 elements / 4 waves when G is streamed, 16 / 2 on the affine path (measured best
+  // 0 = auto: 32 elements / 4 waves when G is streamed, 16 / 4 on the affine path (measured best
   // on MI355X at p=4 fp64, profiles/r01_block_sweep.txt)
   int block_elems = 0, waves = 0;
   bool prof = false;
@@ -1285,7 +1285,7 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
       affine_mesh = false;
   }
   const int be0 = c->block_elems > 0 ? c->block_elems : (affine_mesh ? 16 : 32);
-  int waves = c->waves > 0 ? c->waves : (affine_mesh ? 2 : 4);
+  int waves = c->waves > 0 ? c->waves : 4;
   if (op->P > 4 && waves > 4)
     waves = 4;  // launch bound of the block kernel for the higher degrees
   // blocks must fit the CU's 160 KB of LDS: halve the block size until they do

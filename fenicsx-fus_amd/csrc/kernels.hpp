@@ -341,7 +341,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 // in registers (beyond 256 per lane) and are limited to 4 waves so one wave per SIMD may use the
 // whole 512-entry register file.
 template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM>
-__global__ void __launch_bounds__((P <= 4) ? 512 : 256)
+__global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P <= 4 && GEOM == GEOM_AFFINE) ? 4 : 1)
 k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
            const T* __restrict__ geo, const T* __restrict__ coef, const T* __restrict__ x,
            T* __restrict__ bvec, T* __restrict__ partial, const StageArgs<T> S)

@@ -49,7 +49,7 @@ int fus_init(int device, fus_ctx** ctx);
 int fus_finalize(fus_ctx* ctx);
 int fus_synchronize(fus_ctx* ctx);
 /* Tunables, set before fus_op_create: "block_elems" (elements per LDS block) and "waves"
- * (waves per workgroup; 1, 2, 4 or 8): default 0 = auto (32 / 4 when G is streamed, 16 / 2 on the
+ * (waves per workgroup; 1, 2, 4 or 8): default 0 = auto (32 / 4 when G is streamed, 16 / 4 on the
  * affine path), "geometry" (0 auto | 1 always stream the
  * per-point factors), "fields" (1 | 2: operator inputs the block kernel
  * stages per pass; 2 is required by FUS_LOSSY), "deterministic" (1: elements accumulate in

@@ -1144,7 +1144,7 @@ static int model_getset(fus_model* m, int which, void* host_or_dev, int space, b
 // -------------------------------------------------------------------------------------------------
 // dispatch over (dtype, P)
 // -------------------------------------------------------------------------------------------------
-#ifdef FUS_DEV_BUILD  // developer iteration build: P = 4, fp64 only (never shipped; build.py --dev)
+#ifdef FUS_DEV_BUILD  // developer iteration build: P = 4 only (never shipped; build.py --dev)
 #define FUS_DISPATCH_P(T, P_, CALL)                                                                \
   switch (P_)                                                                                      \
   {                                                                                                \
@@ -1154,10 +1154,16 @@ static int model_getset(fus_model* m, int which, void* host_or_dev, int space, b
 #define FUS_DISPATCH(dtype_, P_, CALL)                                                             \
   do                                                                                               \
   {                                                                                                \
-    if ((dtype_) != FUS_F64)                                                                       \
-      return fail(FUS_ERR_ARG, "dev build: fp64 only");                                            \
-    typedef double TT;                                                                             \
-    FUS_DISPATCH_P(TT, P_, CALL)                                                                   \
+    if ((dtype_) == FUS_F64)                                                                       \
+    {                                                                                              \
+      typedef double TT;                                                                           \
+      FUS_DISPATCH_P(TT, P_, CALL)                                                                 \
+    }                                                                                              \
+    else                                                                                           \
+    {                                                                                              \
+      typedef float TT;                                                                            \
+      FUS_DISPATCH_P(TT, P_, CALL)                                                                 \
+    }                                                                                              \
   } while (0)
 #else
 #define FUS_DISPATCH_P(T, P_, CALL)                                                                \

@@ -1,7 +1,7 @@
 """Shared problem builders for the tests (inputs follow SURVEY 8d / the reference tests' recipes)."""
 import numpy as np
 
-from fenicsxfus_amd import BoxMesh, FunctionSpace, FacetTags, tag_box_boundary
+from fenicsxfus_amd import BoxMesh, FunctionSpace, FacetTags
 
 
 class Problem:

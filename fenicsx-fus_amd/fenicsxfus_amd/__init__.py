@@ -9,3 +9,4 @@ from .models import (LinearSpectralExplicit, LossySpectralExplicit, WesterveltSp
                      compute_diffusivity_of_sound,
                      group_finish_setup, group_rk4_steps)
 from .operators import MassSpectral3D, SpectralOperatorData, StiffnessSpectral3D  # noqa: F401
+from .unstructured import HexFunctionSpace, HexMesh, read_xdmf_hex_mesh  # noqa: F401,E402

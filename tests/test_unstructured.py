@@ -1,0 +1,103 @@
+"""Unstructured meshes: the reference's own Gmsh fixture (cpp/fenicsx-sf/tests/test_operators3d/
+mesh.xdmf, committed as data in tests/golden/ref_test_operators3d_mesh.npz) read by this
+repository's XDMF/HDF5 reader, the geometric tensor-dofmap builder, and the operators on it with the
+reference test's input recipe (main.cpp:60-67, 78-79, 85, 129)."""
+import os
+
+import numpy as np
+import pytest
+
+import fenicsxfus_amd as fa
+from fenicsxfus_amd.unstructured import VTK_TO_TENSOR, HexFunctionSpace, HexMesh, read_xdmf_hex_mesh
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_test_operators3d_mesh.npz")
+REF_XDMF = "/root/reference/cpp/fenicsx-sf/tests/test_operators3d/mesh.xdmf"
+
+
+@pytest.fixture(scope="module")
+def ref_mesh():
+    g = np.load(GOLD)
+    mesh = HexMesh(g["geometry"], g["topology_vtk"][:, VTK_TO_TENSOR])
+    tags = mesh.facet_tags(g["facet_topology"], g["facet_values"])
+    return mesh, tags
+
+
+def test_xdmf_hdf5_reader_matches_fixture():
+    if not os.path.exists(REF_XDMF):
+        pytest.skip("reference tree absent")
+    mesh, cell_vals, tags = read_xdmf_hex_mesh(REF_XDMF)
+    g = np.load(GOLD)
+    assert np.array_equal(mesh.geometry.x, g["geometry"])
+    assert np.array_equal(mesh.geometry.dofmap, g["topology_vtk"][:, VTK_TO_TENSOR])
+    assert np.array_equal(cell_vals, g["cell_values"]) and len(tags.cells) == len(g["facet_values"])
+
+
+def test_reference_mesh_space_and_oracle_kats(orc, ref_mesh):
+    mesh, tags = ref_mesh
+    assert mesh.num_cells == 6312 and mesh.entity_counts() == (7939, 21624, 19998, 6312)
+    assert len(tags.cells) == 2124 and set(tags.values.tolist()) == {1}
+    V = HexFunctionSpace(mesh, 4)            # raises unless #dofs matches the topological count
+    assert V.num_dofs == 7939 + 3 * 21624 + 9 * 19998 + 27 * 6312
+    wts, D = orc.gll_weights_at(V.nodes1d), orc.dphi(V.nodes1d)
+    G, dJ = orc.geometry(3, mesh.geometry.x, mesh.geometry.dofmap, V.nodes1d, wts)
+    assert abs(dJ.sum() - 1.0) < 1e-13                       # unit cube
+    n, nc = V.num_dofs, mesh.num_cells
+    K = lambda x: orc.stiffness(3, 5, V.tensor_dofmap, G, D, np.ones(nc), x, np.zeros(n))  # noqa: E731
+    assert np.abs(K(np.ones(n))).max() < 1e-14
+    X = V.tabulate_dof_coordinates()
+    u = np.sin(X[:, 0]) * np.cos(np.pi * X[:, 1])            # the reference test's input function
+    exact = (0.5 + np.sin(2) / 4) * 0.5 + np.pi**2 * (0.5 - np.sin(2) / 4) * 0.5   # int |grad u|^2
+    assert abs(u @ K(u) - exact) < 1e-9 * exact              # spectral accuracy on the Gmsh mesh
+    area = orc.facet_diag(3, tags.cells, tags.local_facets, np.ones(nc), mesh.geometry.x, mesh.geometry.dofmap,
+                          V.nodes1d, wts, V.tensor_dofmap, n).sum()
+    assert abs(area - 6.0) < 1e-12
+
+
+def test_layout_on_unstructured_mesh(ref_mesh):
+    mesh, _ = ref_mesh
+    V = HexFunctionSpace(mesh, 3)
+    info = fa.layout_check(3, V.tensor_dofmap, mesh.cell_centroids(), block_elems=32, waves=4)
+    assert info[1] + info[2] == V.num_dofs and info[0] == -(-mesh.num_cells // 32)
+
+
+@pytest.mark.gpu
+def test_reference_operator_test_on_its_own_mesh(orc, ref_mesh):
+    """cpp/fenicsx-sf/tests/test_operators3d/main.cpp with its Gmsh mesh (the commented read_mesh
+    block :40-48): P = 4, u = sin(x) cos(pi y), c0 = 1.5e-3, rho0 = 1e-3, mass coefficient 1/(rho c^2),
+    stiffness coefficient -1/rho; HIP operators vs the oracle, then 10 Linear RK4 steps."""
+    mesh, tags = ref_mesh
+    P = 4
+    V = HexFunctionSpace(mesh, P)
+    n, nc = V.num_dofs, mesh.num_cells
+    wts, D = orc.gll_weights_at(V.nodes1d), orc.dphi(V.nodes1d)
+    G, dJ = orc.geometry(3, mesh.geometry.x, mesh.geometry.dofmap, V.nodes1d, wts)
+    X = V.tabulate_dof_coordinates()
+    u = np.sin(X[:, 0]) * np.cos(np.pi * X[:, 1])
+    c0, rho0 = 1.5e-3, 1e-3
+    ctx = fa.Context(0)
+    d = fa.SpectralOperatorData(V, ctx)
+    assert not d.is_affine()
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()  # noqa: E731
+    mc, sc = np.full(nc, 1 / rho0 / c0 / c0), np.full(nc, -1 / rho0)
+    assert rel(d.mass(u, mc, np.zeros(n)), orc.mass(3, P + 1, V.tensor_dofmap, dJ, mc, u, np.zeros(n))) < 1e-14
+    assert rel(d.stiffness(u, sc, np.zeros(n)),
+               orc.stiffness(3, P + 1, V.tensor_dofmap, G, D, sc, u, np.zeros(n), fast=True)) < 1e-12
+    Gd, dJd = d.geometry()
+    assert rel(Gd, G) < 1e-12 and rel(dJd, dJ) < 1e-13
+    d.close()
+    # Linear model, water, every boundary facet is tag 1 (source) in this file
+    c, rho = np.full(nc, 1500.0), np.full(nc, 1000.0)
+    m = orc.mass(3, P + 1, V.tensor_dofmap, dJ, 1 / (rho * c * c), np.ones(n), np.zeros(n))
+    src = orc.facet_diag(3, tags.cells, tags.local_facets, 1 / rho, mesh.geometry.x, mesh.geometry.dofmap, V.nodes1d,
+                         wts, V.tensor_dofmap, n)
+    hmin = np.cbrt(dJ.reshape(nc, -1).sum(axis=1)).min()
+    dt = 0.2 * hmin / (1500.0 * P**2)
+    uo, vo = np.zeros(n), np.zeros(n)
+    orc.linear_rk4(3, P + 1, V.tensor_dofmap, G, D, -1 / rho, m, src, np.zeros(n), 5e3, 6e4, 1500.0, 0.0,
+                   10 * dt * (1 - 1e-9), dt, uo, vo, fast=True)
+    model = fa.LinearSpectralExplicit(mesh, tags, P, c, rho, 5e3, 6e4, 1500.0, 4, dt, V=V, ctx=ctx)
+    model.init()
+    un, vn, _ = model.rk(0.0, 10 * dt * (1 - 1e-9))
+    assert np.abs(uo).max() > 0 and rel(un.x.array, uo) < 1e-10 and rel(vn.x.array, vo) < 1e-10
+    model.close()
+    ctx.close()

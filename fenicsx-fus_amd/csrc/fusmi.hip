@@ -564,7 +564,6 @@ static int op_apply(fus_op* op, const void* x, const void* coeffs, void* y, int 
 {
   fus_ctx* c = op->ctx;
   hipStream_t st = c->stream;
-  Layout& L = op->L;
   T* xin = static_cast<T*>(op->d_tmp_x);
   T* bint = static_cast<T*>(op->d_tmp_b);
   T* tc = static_cast<T*>(op->d_tmp_c);
@@ -595,7 +594,6 @@ static int op_apply(fus_op* op, const void* x, const void* coeffs, void* y, int 
                        op->d_dof_perm, bint, static_cast<T*>(y));
   HIPCHK(hipGetLastError());
   HIPCHK(hipStreamSynchronize(st));
-  (void)L;
   return FUS_OK;
 }
 
@@ -1669,8 +1667,6 @@ int fus_op_set_neighbours(fus_op* op, int nneigh, const int32_t* ranks, const in
   uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
   op->n_uidx = (int64_t)uniq.size();
   std::vector<std::vector<int32_t>> addends(uniq.size());
-  bool own_done_for_rank = false;
-  (void)own_done_for_rank;
   for (size_t n = 0; n < op->neigh.size(); ++n)
   {
     const Neigh& nb = op->neigh[n];

@@ -101,3 +101,27 @@ def test_reference_operator_test_on_its_own_mesh(orc, ref_mesh):
     assert np.abs(uo).max() > 0 and rel(un.x.array, uo) < 1e-10 and rel(vn.x.array, vo) < 1e-10
     model.close()
     ctx.close()
+
+
+def test_point_evaluation(ref_mesh):
+    """evaluate(): a polynomial of the space's degree in PHYSICAL coordinates is not in the space on
+    non-affine cells, but a trilinear-mapped field is reproduced; use an affine box for exactness and
+    the Gmsh mesh for the locate/Newton machinery (smooth field, spectral accuracy)."""
+    from fenicsxfus_amd.evaluate import evaluate, locate
+
+    box = fa.BoxMesh([0, 0, 0], [1.0, 0.8, 0.6], (3, 2, 2))
+    Vb = fa.FunctionSpace(box, 4)
+    Xd = Vb.tabulate_dof_coordinates()
+    f = lambda X: X[:, 0] ** 4 - 2 * X[:, 1] ** 3 * X[:, 2] + X[:, 0] * X[:, 1] * X[:, 2] ** 2 + 1.0  # noqa: E731
+    rng = np.random.default_rng(0)
+    pts = rng.uniform([0, 0, 0], [1.0, 0.8, 0.6], size=(200, 3))
+    assert np.abs(evaluate(Vb, f(Xd), pts) - f(pts)).max() < 1e-13
+    assert np.isnan(evaluate(Vb, f(Xd), np.array([[1.5, 0.1, 0.1]]))).all()
+    mesh, _ = ref_mesh
+    V = HexFunctionSpace(mesh, 4)
+    X = V.tabulate_dof_coordinates()
+    u = np.sin(X[:, 0]) * np.cos(np.pi * X[:, 1])
+    pts = rng.uniform(0.02, 0.98, size=(300, 3))
+    cell, _ = locate(mesh, pts)
+    assert (cell >= 0).all()
+    assert np.abs(evaluate(V, u, pts) - np.sin(pts[:, 0]) * np.cos(np.pi * pts[:, 1])).max() < 1e-6

@@ -1288,7 +1288,11 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
     if (std::sqrt(e2 / h2) > 0.5 * tol)
       affine_mesh = false;
   }
-  const int be0 = c->block_elems > 0 ? c->block_elems : (affine_mesh ? 16 : 32);
+  // auto block size: about 2-3 thousand local dofs per block when G is streamed (128 / 64 / 32
+  // elements at P = 2 / 3 / >= 4; larger P shrink further to fit LDS), half of that on the affine
+  // path (profiles/r01_block_sweep.txt)
+  const int be_stream = op->P == 2 ? 128 : (op->P == 3 ? 64 : 32);
+  const int be0 = c->block_elems > 0 ? c->block_elems : (affine_mesh ? be_stream / 2 : be_stream);
   int waves = c->waves > 0 ? c->waves : 4;
   if (op->P > 4 && waves > 4)
     waves = 4;  // launch bound of the block kernel for the higher degrees

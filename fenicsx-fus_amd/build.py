@@ -14,24 +14,59 @@ DEPS = SRC + [os.path.join(HERE, "csrc", f) for f in ("kernels.hpp", "layout.hpp
 OUT = os.path.join(HERE, "fenicsxfus_amd", "libfusmi.so")
 
 
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-function",
+         "-munsafe-fp-atomics"]
+DEGREES = (2, 3, 4, 5, 6, 7)
+
+
+def _compile_units(objdir, degrees, extra, verbose):
+    """fusmi.hip is compiled once per polynomial degree (-DFUS_TU_DEGREE=k: the block kernels of
+    that degree) and once as the main unit (C ABI + degree-independent code), concurrently."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = [([hipcc, *FLAGS, *extra, "-c", SRC[0], "-o", os.path.join(objdir, "fusmi_main.o")]),
+            ([hipcc, *FLAGS, *extra, "-c", SRC[1], "-o", os.path.join(objdir, "layout.o")])]
+    for k in degrees:
+        jobs.append([hipcc, *FLAGS, *extra, f"-DFUS_TU_DEGREE={k}", "-c", SRC[0], "-o",
+                     os.path.join(objdir, f"fusmi_p{k}.o")])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"{' '.join(cmd)}\n{r.stdout}")
+        return cmd[-1]
+
+    workers = int(os.environ.get("FUSMI_BUILD_JOBS", min(len(jobs), os.cpu_count() or 1)))
+    # heaviest units first so the pool stays busy
+    order = jobs[2:][::-1] + jobs[:2]
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        return list(ex.map(run, order))
+
+
+def _link(objs, out, verbose):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # RCCL is bound at run time (fusmi.hip rccl_load)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out, "-ldl", "-Wl,-rpath,/opt/rocm/lib"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+
+
 def build(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
-    """dev=True: P=4/fp64-only iteration build into abl/libfusmi_dev.so (use with FUSMI_LIB)."""
+    """dev=True: P=4-only iteration build into abl/libfusmi_dev.so (use with FUSMI_LIB)."""
+    objroot = os.path.join(HERE, "_build")
     if dev:
         out = os.path.join(HERE, "..", "abl", "libfusmi_dev.so")
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-                               "-Wno-unused-value", "-munsafe-fp-atomics", "-DFUS_DEV_BUILD", *SRC, "-o", out,
-                               "-ldl", "-Wl,-rpath,/opt/rocm/lib"])
+        _link(_compile_units(os.path.join(objroot, "dev"), (4,), ["-DFUS_DEV_BUILD"], verbose), out, verbose)
         return out
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-value", "-munsafe-fp-atomics", *SRC,
-           "-o", OUT, "-ldl", "-Wl,-rpath,/opt/rocm/lib"]  # RCCL is bound at run time (fusmi.hip rccl_load)
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+    _link(_compile_units(os.path.join(objroot, "full"), DEGREES, [], verbose), OUT, verbose)
     return OUT
 
 

@@ -28,7 +28,15 @@ using namespace fus;
 // -------------------------------------------------------------------------------------------------
 // errors
 // -------------------------------------------------------------------------------------------------
-static thread_local std::string g_err;
+// One shared object is linked from several translation units of this file: the "main" unit (C ABI,
+// degree-independent code) and one unit per polynomial degree (-DFUS_TU_DEGREE=k) holding the
+// k_block_op instantiations of that degree, so that the degrees compile in parallel (build.py).
+#define FUS_HIDDEN __attribute__((visibility("hidden")))
+#ifdef FUS_TU_DEGREE
+extern FUS_HIDDEN thread_local std::string g_err;
+#else
+FUS_HIDDEN thread_local std::string g_err;
+#endif
 static int fail(int code, const std::string& msg)
 {
   g_err = msg;
@@ -73,7 +81,10 @@ struct RcclApi
   ncclResult_t (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
-static RcclApi g_rccl;
+#ifdef FUS_TU_DEGREE
+extern FUS_HIDDEN RcclApi g_rccl;
+#else
+FUS_HIDDEN RcclApi g_rccl;
 
 static int rccl_load()
 {
@@ -108,6 +119,7 @@ static int rccl_load()
   g_rccl = a;
   return FUS_OK;
 }
+#endif  // !FUS_TU_DEGREE
 
 // -------------------------------------------------------------------------------------------------
 // handles
@@ -1140,83 +1152,100 @@ static int model_getset(fus_model* m, int which, void* host_or_dev, int space, b
 }
 
 // -------------------------------------------------------------------------------------------------
-// dispatch over (dtype, P)
+// dispatch over (dtype, P): the degree-dependent entry points live in the per-degree units
 // -------------------------------------------------------------------------------------------------
-#ifdef FUS_DEV_BUILD  // developer iteration build: P = 4 only (never shipped; build.py --dev)
-#define FUS_DISPATCH_P(T, P_, CALL)                                                                \
-  switch (P_)                                                                                      \
-  {                                                                                                \
-  case 4: { constexpr int PP = 4; return CALL; }                                                   \
-  default: return fail(FUS_ERR_ARG, "dev build: P = 4 only");                                      \
-  }
-#define FUS_DISPATCH(dtype_, P_, CALL)                                                             \
-  do                                                                                               \
-  {                                                                                                \
-    if ((dtype_) == FUS_F64)                                                                       \
-    {                                                                                              \
-      typedef double TT;                                                                           \
-      FUS_DISPATCH_P(TT, P_, CALL)                                                                 \
-    }                                                                                              \
-    else                                                                                           \
-    {                                                                                              \
-      typedef float TT;                                                                            \
-      FUS_DISPATCH_P(TT, P_, CALL)                                                                 \
-    }                                                                                              \
-  } while (0)
-#else
-#define FUS_DISPATCH_P(T, P_, CALL)                                                                \
-  switch (P_)                                                                                      \
-  {                                                                                                \
-  case 2: { constexpr int PP = 2; return CALL; }                                                   \
-  case 3: { constexpr int PP = 3; return CALL; }                                                   \
-  case 4: { constexpr int PP = 4; return CALL; }                                                   \
-  case 5: { constexpr int PP = 5; return CALL; }                                                   \
-  case 6: { constexpr int PP = 6; return CALL; }                                                   \
-  case 7: { constexpr int PP = 7; return CALL; }                                                   \
-  default: return fail(FUS_ERR_ARG, "unsupported polynomial degree (2..7)");                       \
-  }
-#define FUS_DISPATCH(dtype_, P_, CALL)                                                             \
-  do                                                                                               \
-  {                                                                                                \
-    if ((dtype_) == FUS_F64)                                                                       \
-    {                                                                                              \
-      typedef double TT;                                                                           \
-      FUS_DISPATCH_P(TT, P_, CALL)                                                                 \
-    }                                                                                              \
-    else                                                                                           \
-    {                                                                                              \
-      typedef float TT;                                                                            \
-      FUS_DISPATCH_P(TT, P_, CALL)                                                                 \
-    }                                                                                              \
-  } while (0)
-#endif
+struct DegreeImpl
+{
+  int (*op_setup)(fus_op*);
+  int (*op_apply)(fus_op*, int, const void*, const void*, void*, int);
+  int (*op_get_geometry)(fus_op*, void*, void*);
+  int (*model_setup)(fus_model*, const void*, const void*, const void*, const void*, int64_t,
+                     const int32_t*, const int32_t*, const int32_t*);
+  int (*model_step)(fus_model*, double, double);
+  int (*stage_begin)(fus_model*, int, double, double);
+};
+#define FUS_CAT_(a, b) a##b
+#define FUS_CAT(a, b) FUS_CAT_(a, b)
 
-static int d_op_setup(fus_op* op) { FUS_DISPATCH(op->dtype, op->P, (op_setup_device<TT, PP>(op))); }
+#ifdef FUS_TU_DEGREE
+template <typename T, int P>
+static int op_apply_kind(fus_op* op, int kind, const void* x, const void* cf, void* y, int space)
+{
+  return kind == OP_STIFFNESS ? op_apply<T, P, OP_STIFFNESS>(op, x, cf, y, space)
+                              : op_apply<T, P, OP_MASS>(op, x, cf, y, space);
+}
+template <typename T, int P>
+static DegreeImpl make_degree_impl()
+{
+  return {&op_setup_device<T, P>, &op_apply_kind<T, P>, &op_get_geometry<T, P>,
+          &model_setup<T, P>,     &model_step<T, P>,    &stage_begin<T, P>};
+}
+FUS_HIDDEN const DegreeImpl* FUS_CAT(fus_degree_impl_, FUS_TU_DEGREE)(int dtype)
+{
+  static const DegreeImpl f64 = make_degree_impl<double, FUS_TU_DEGREE>();
+  static const DegreeImpl f32 = make_degree_impl<float, FUS_TU_DEGREE>();
+  return dtype == FUS_F64 ? &f64 : &f32;
+}
+#else  // main unit: everything from here to the end of the file
+FUS_HIDDEN const DegreeImpl* fus_degree_impl_4(int);
+#ifndef FUS_DEV_BUILD  // developer iteration build: P = 4 only (never shipped; build.py --dev)
+FUS_HIDDEN const DegreeImpl* fus_degree_impl_2(int);
+FUS_HIDDEN const DegreeImpl* fus_degree_impl_3(int);
+FUS_HIDDEN const DegreeImpl* fus_degree_impl_5(int);
+FUS_HIDDEN const DegreeImpl* fus_degree_impl_6(int);
+FUS_HIDDEN const DegreeImpl* fus_degree_impl_7(int);
+#endif
+static const DegreeImpl* degree_impl(int dtype, int P)
+{
+  switch (P)
+  {
+  case 4: return fus_degree_impl_4(dtype);
+#ifndef FUS_DEV_BUILD
+  case 2: return fus_degree_impl_2(dtype);
+  case 3: return fus_degree_impl_3(dtype);
+  case 5: return fus_degree_impl_5(dtype);
+  case 6: return fus_degree_impl_6(dtype);
+  case 7: return fus_degree_impl_7(dtype);
+#endif
+  default: return nullptr;
+  }
+}
+#define FUS_DEGREE(d, dtype_, P_)                                                                  \
+  const DegreeImpl* d = degree_impl(dtype_, P_);                                                   \
+  if (!d)                                                                                          \
+    return fail(FUS_ERR_ARG, "unsupported polynomial degree (2..7)");
+
+static int d_op_setup(fus_op* op)
+{
+  FUS_DEGREE(d, op->dtype, op->P);
+  return d->op_setup(op);
+}
 static int d_op_apply(fus_op* op, int kind, const void* x, const void* cf, void* y, int space)
 {
-  if (kind == OP_STIFFNESS)
-    FUS_DISPATCH(op->dtype, op->P, (op_apply<TT, PP, OP_STIFFNESS>(op, x, cf, y, space)));
-  else
-    FUS_DISPATCH(op->dtype, op->P, (op_apply<TT, PP, OP_MASS>(op, x, cf, y, space)));
+  FUS_DEGREE(d, op->dtype, op->P);
+  return d->op_apply(op, kind, x, cf, y, space);
 }
 static int d_op_get_geometry(fus_op* op, void* G, void* dJ)
 {
-  FUS_DISPATCH(op->dtype, op->P, (op_get_geometry<TT, PP>(op, G, dJ)));
+  FUS_DEGREE(d, op->dtype, op->P);
+  return d->op_get_geometry(op, G, dJ);
 }
 static int d_model_setup(fus_model* m, const void* c0, const void* rho0, const void* delta0,
                          const void* beta0, int64_t nf, const int32_t* fc, const int32_t* fl,
                          const int32_t* ft)
 {
-  FUS_DISPATCH(m->op->dtype, m->op->P,
-               (model_setup<TT, PP>(m, c0, rho0, delta0, beta0, nf, fc, fl, ft)));
+  FUS_DEGREE(d, m->op->dtype, m->op->P);
+  return d->model_setup(m, c0, rho0, delta0, beta0, nf, fc, fl, ft);
 }
 static int d_model_step(fus_model* m, double t, double dt)
 {
-  FUS_DISPATCH(m->op->dtype, m->op->P, (model_step<TT, PP>(m, t, dt)));
+  FUS_DEGREE(d, m->op->dtype, m->op->P);
+  return d->model_step(m, t, dt);
 }
 static int d_stage_begin(fus_model* m, int i, double t, double dt)
 {
-  FUS_DISPATCH(m->op->dtype, m->op->P, (stage_begin<TT, PP>(m, i, t, dt)));
+  FUS_DEGREE(d, m->op->dtype, m->op->P);
+  return d->stage_begin(m, i, t, dt);
 }
 static int d_stage_end(fus_model* m, int i, double t, double dt)
 {
@@ -2008,3 +2037,4 @@ int fus_profile_get(fus_ctx* c, const char* name, double* total_ms, int64_t* cou
 }
 
 } // extern "C"
+#endif  // !FUS_TU_DEGREE

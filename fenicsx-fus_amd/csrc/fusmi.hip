@@ -161,13 +161,14 @@ struct fus_op
 {
   fus_ctx* ctx;
   int P, N, Nd, dtype;
+  int tdim = 3;  // 3: hexahedra, 2: quadrilaterals (Nd = N^tdim)
   size_t ts;  // sizeof(T)
   int64_t ncells, ndofs, nnodes;
   Layout L;
   std::vector<double> nodes, wts, D;
   std::vector<char> h_geom_x;        // caller geometry (host copy, T)
   std::vector<int32_t> h_geom_dm;    // [ncells*geom_nv]
-  int geom_order = 1, geom_nv = 8;   // 1: 8 vertices; 2: 27 nodes in tensor order
+  int geom_order = 1, geom_nv = 8;   // 1: 2^tdim vertices; 2: 27 nodes in tensor order (hexahedra)
   std::vector<int32_t> h_dofmap;     // caller tensor dofmap
   // device
   BlockArgs A{};
@@ -275,7 +276,7 @@ struct ProfScope
 // -------------------------------------------------------------------------------------------------
 // typed implementation
 // -------------------------------------------------------------------------------------------------
-template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM>
+template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3>
 static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec,
                              const StageArgs<T>& S)
 {
@@ -286,11 +287,11 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
   static bool attr_set = false;  // per instantiation
   if (!attr_set)
   {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM>), dim3(op->L.nblocks),
+  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD>), dim3(op->L.nblocks),
                      dim3(64 * op->L.waves), op->lds_bytes, op->ctx->stream, op->A, Dk,
                      static_cast<const T*>(op->d_Dg), geo, coef, x, bvec,
                      static_cast<T*>(op->d_partial), S);
@@ -304,6 +305,10 @@ static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, 
 {
   if (NF > op->nfields)
     return fail(FUS_ERR_STATE, "operator data was not created for two-field models (option fields=2)");
+  if (op->tdim == 2)  // quadrilaterals: streamed geometry only
+    return op->deterministic
+               ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_STREAM, 2>(op, geo, coef, x, bvec, S)
+               : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_STREAM, 2>(op, geo, coef, x, bvec, S);
   // geometry operand: per-cell factors (affine meshes) or the streamed per-point arrays
   if (op->affine)
   {
@@ -451,13 +456,19 @@ static int halo_exchange_local(fus_op** ops, int n)
 template <typename T, int P>
 static int ensure_stream_geometry(fus_op* op)
 {
-  constexpr int N = P + 1, Nd = N * N * N;
+  constexpr int N = P + 1;
   if (op->d_G)
     return FUS_OK;
   hipStream_t st = op->ctx->stream;
-  FUSCHK(dalloc_bytes(op->allocs, &op->d_G, (size_t)op->ncells * 6 * Nd * sizeof(T), false, st));
+  const int Nd = op->Nd, ng = op->tdim == 3 ? 6 : 3;
+  FUSCHK(dalloc_bytes(op->allocs, &op->d_G, (size_t)op->ncells * ng * Nd * sizeof(T), false, st));
   FUSCHK(dalloc_bytes(op->allocs, &op->d_detJ, (size_t)op->ncells * Nd * sizeof(T), false, st));
-  if (op->geom_order == 1)
+  if (op->tdim == 2)
+    hipLaunchKernelGGL((k_geometry2d<T, N>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st,
+                       op->ncells, op->d_cell_perm, static_cast<const T*>(op->d_xg), op->d_xdm,
+                       static_cast<const double*>(op->d_pts), static_cast<const double*>(op->d_wts),
+                       static_cast<T*>(op->d_G), static_cast<T*>(op->d_detJ));
+  else if (op->geom_order == 1)
     hipLaunchKernelGGL((k_geometry<T, N, 1>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st,
                        op->ncells, op->d_cell_perm, static_cast<const T*>(op->d_xg), op->d_xdm,
                        static_cast<const double*>(op->d_pts), static_cast<const double*>(op->d_wts),
@@ -474,7 +485,7 @@ static int ensure_stream_geometry(fus_op* op)
 template <typename T, int P>
 static int op_setup_device(fus_op* op)
 {
-  constexpr int N = P + 1, Nd = N * N * N;
+  constexpr int N = P + 1;
   fus_ctx* c = op->ctx;
   hipStream_t st = c->stream;
   Layout& L = op->L;
@@ -544,7 +555,7 @@ static int op_setup_device(fus_op* op)
   FUSCHK(dalloc(pool, &d_err, 1));
   HIPCHK(hipMemsetAsync(d_err, 0, sizeof(unsigned int), st));
   float rel_err = 1.0f;
-  if (op->geom_order == 1)
+  if (op->geom_order == 1 && op->tdim == 3)
   {
     hipLaunchKernelGGL((k_geometry_affine<T>), dim3(nblk(op->ncells)), dim3(256), 0, st, op->ncells,
                        op->d_cell_perm, d_xg, op->d_xdm, d_Gc, d_err);
@@ -612,21 +623,27 @@ static int op_apply(fus_op* op, const void* x, const void* coeffs, void* y, int 
 template <typename T, int P>
 static int op_get_geometry(fus_op* op, void* G, void* detJ)
 {
-  constexpr int N = P + 1, Nd = N * N * N;
+  constexpr int N = P + 1;
   hipStream_t st = op->ctx->stream;
   FUSCHK((ensure_stream_geometry<T, P>(op)));
+  const int Nd = op->Nd, ng = op->tdim == 3 ? 6 : 3;
   std::vector<void*> tmp;
   T *dG = nullptr, *dd = nullptr;
   if (G)
-    FUSCHK(dalloc(tmp, &dG, (size_t)op->ncells * Nd * 6));
+    FUSCHK(dalloc(tmp, &dG, (size_t)op->ncells * Nd * ng));
   if (detJ)
     FUSCHK(dalloc(tmp, &dd, (size_t)op->ncells * Nd));
-  hipLaunchKernelGGL((k_geometry_export<T, N>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st,
-                     op->ncells, op->d_cell_perm, static_cast<const T*>(op->d_G),
-                     static_cast<const T*>(op->d_detJ), dG, dd);
+  if (op->tdim == 2)
+    hipLaunchKernelGGL((k_geometry_export2d<T, N>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st,
+                       op->ncells, op->d_cell_perm, static_cast<const T*>(op->d_G),
+                       static_cast<const T*>(op->d_detJ), dG, dd);
+  else
+    hipLaunchKernelGGL((k_geometry_export<T, N>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st,
+                       op->ncells, op->d_cell_perm, static_cast<const T*>(op->d_G),
+                       static_cast<const T*>(op->d_detJ), dG, dd);
   HIPCHK(hipGetLastError());
   if (G)
-    HIPCHK(hipMemcpyAsync(G, dG, (size_t)op->ncells * Nd * 6 * sizeof(T), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(G, dG, (size_t)op->ncells * Nd * ng * sizeof(T), hipMemcpyDeviceToHost, st));
   if (detJ)
     HIPCHK(hipMemcpyAsync(detJ, dd, (size_t)op->ncells * Nd * sizeof(T), hipMemcpyDeviceToHost, st));
   HIPCHK(hipStreamSynchronize(st));
@@ -650,6 +667,31 @@ static void facet_diag_host(const fus_op* op, int64_t nfacets, const int32_t* fc
       i_lo = i;
     if (op->nodes[i] > op->nodes[i_hi])
       i_hi = i;
+  }
+  if (op->tdim == 2)
+  {
+    // edges of quadrilaterals (local facet 0: y=0, 1: x=0, 2: x=1, 3: y=1): weight = edge-length
+    // element |dx/dX_t| times the 1-D quadrature weight
+    static const int axis2[4] = {1, 0, 0, 1}, side2[4] = {0, 0, 1, 1};
+    for (int64_t f = 0; f < nfacets; ++f)
+    {
+      const int64_t cell = fc[f];
+      const int ax = axis2[fl[f]], sd = side2[fl[f]], d1 = 1 - ax;
+      T cd[4][3];
+      for (int v = 0; v < 4; ++v)
+        for (int j = 0; j < 3; ++j)
+          cd[v][j] = xg[3 * (int64_t)op->h_geom_dm[cell * 4 + v] + j];
+      for (int a = 0; a < N; ++a)
+      {
+        int idx[2];
+        idx[ax] = sd ? i_hi : i_lo, idx[d1] = a;
+        T J[2][2];
+        jacobian2<T>(cd, op->nodes[idx[0]], op->nodes[idx[1]], J);
+        const T len = (T)std::sqrt((double)(J[0][d1] * J[0][d1] + J[1][d1] * J[1][d1]));
+        out[op->h_dofmap[cell * Nd + idx[0] * N + idx[1]]] += cellcoef[cell] * len * (T)op->wts[a];
+      }
+    }
+    return;
   }
   for (int64_t f = 0; f < nfacets; ++f)
   {
@@ -1293,7 +1335,7 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
       }
   // will the per-cell (affine) geometry path be taken?  (same test as k_geometry_affine, on the host
   // copy: every vertex of every cell on the parallelepiped spanned by vertices 0, 1, 2, 4)
-  bool affine_mesh = c->geometry == 0 && op->geom_order == 1;
+  bool affine_mesh = c->geometry == 0 && op->geom_order == 1 && op->tdim == 3;
   for (int64_t cidx = 0; cidx < op->ncells && affine_mesh; ++cidx)
   {
     double cd[8][3], h2 = 0, e2 = 0;
@@ -1320,7 +1362,9 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   // auto block size: about 2-3 thousand local dofs per block when G is streamed (128 / 64 / 32
   // elements at P = 2 / 3 / >= 4; larger P shrink further to fit LDS), half of that on the affine
   // path (profiles/r01_block_sweep.txt)
-  const int be_stream = op->P == 2 ? 128 : (op->P == 3 ? 64 : 32);
+  // quadrilaterals: N^2 nodes per element, so many more elements make a block of that size
+  static const int be_quad[8] = {0, 0, 512, 256, 256, 128, 128, 64};
+  const int be_stream = op->tdim == 2 ? be_quad[op->P] : (op->P == 2 ? 128 : (op->P == 3 ? 64 : 32));
   const int be0 = c->block_elems > 0 ? c->block_elems : (affine_mesh ? be_stream / 2 : be_stream);
   int waves = c->waves > 0 ? c->waves : 4;
   if (op->P > 4 && waves > 4)
@@ -1329,7 +1373,7 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   for (int be = be0;; be = (be + 1) / 2)
   {
     std::string err = build_layout(op->L, op->P, op->ncells, op->ndofs, op->h_dofmap.data(),
-                                   cen.data(), be, waves, force_shared);
+                                   cen.data(), be, waves, force_shared, op->tdim);
     const bool too_big = err.empty() ? op->L.lds_bytes(op->ts, op->nfields) + 64 > 160 * 1024
                                      : err.find("65535") != std::string::npos;
     if (too_big && be > 1)
@@ -1510,8 +1554,10 @@ int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_
 {
   if (!c || !out || !tensor_dofmap || !nodes1d || !geom_x || !geom_dofmap)
     return fail(FUS_ERR_ARG, "null argument");
-  if (tdim != 3)
-    return fail(FUS_ERR_ARG, "only tdim = 3 (hexahedra) is offloaded");
+  if (tdim != 2 && tdim != 3)
+    return fail(FUS_ERR_ARG, "tdim must be 3 (hexahedra) or 2 (quadrilaterals)");
+  if (tdim == 2 && geom_order != 1)
+    return fail(FUS_ERR_ARG, "quadrilateral meshes need first-order (4-vertex) geometry");
   if (P < 2 || P > 7)
     return fail(FUS_ERR_ARG, "unsupported polynomial degree (2..7)");
   if (dtype != FUS_F64 && dtype != FUS_F32)
@@ -1527,7 +1573,8 @@ int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_
   std::unique_ptr<fus_op> op(new fus_op());
   op->deterministic = c->deterministic;
   op->nfields = c->fields;
-  op->ctx = c, op->P = P, op->N = N, op->Nd = N * N * N, op->dtype = dtype;
+  op->ctx = c, op->P = P, op->N = N, op->tdim = tdim, op->dtype = dtype;
+  op->Nd = tdim == 3 ? N * N * N : N * N;
   op->ts = dtype == FUS_F64 ? 8 : 4;
   op->ncells = ncells, op->ndofs = ndofs, op->nnodes = nnodes;
   op->nodes.assign(nodes1d, nodes1d + N);
@@ -1535,7 +1582,7 @@ int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_
   op->D = dphi_table(N, nodes1d);
   op->h_geom_x.assign(static_cast<const char*>(geom_x),
                       static_cast<const char*>(geom_x) + (size_t)nnodes * 3 * op->ts);
-  op->geom_order = geom_order, op->geom_nv = geom_order == 1 ? 8 : 27;
+  op->geom_order = geom_order, op->geom_nv = geom_order == 2 ? 27 : (tdim == 3 ? 8 : 4);
   op->h_geom_dm.assign(geom_dofmap, geom_dofmap + ncells * op->geom_nv);
   op->h_dofmap.assign(tensor_dofmap, tensor_dofmap + ncells * op->Nd);
   for (int64_t k = 0; k < ncells * op->geom_nv; ++k)

@@ -96,4 +96,40 @@ FUS_HD inline T geometric_factor3(const T J[3][3], T w, T G6[6])
   return dw;
 }
 
+// ---- quadrilaterals (cpp/fenicsx-sf-naive/common/precompute.hpp, the 2-D operators of SURVEY a-5) ----
+// cd[v][i]: coordinates of vertex v = vx + 2 vy (the third component is carried but unused).
+template <typename T>
+FUS_HD inline void jacobian2(const T cd[4][3], double X0, double X1, T J[2][2])
+{
+  const double X[2] = {X0, X1};
+  J[0][0] = J[0][1] = J[1][0] = J[1][1] = 0;
+  for (int v = 0; v < 4; ++v)
+  {
+    T f[2], df[2];
+    for (int d = 0; d < 2; ++d)
+    {
+      const int bit = (v >> d) & 1;
+      f[d] = (T)(bit ? X[d] : 1.0 - X[d]);
+      df[d] = (T)(bit ? 1.0 : -1.0);
+    }
+    const T g[2] = {df[0] * f[1], f[0] * df[1]};
+    for (int i = 0; i < 2; ++i)
+      for (int j = 0; j < 2; ++j)
+        J[i][j] += cd[v][i] * g[j];
+  }
+}
+
+// G3 = (xx, xy, yy) of K K^T |det J| w; returns |det J| w
+template <typename T>
+FUS_HD inline T geometric_factor2(const T J[2][2], T w, T G3[3])
+{
+  const T det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+  const T K00 = J[1][1] / det, K01 = -J[0][1] / det, K10 = -J[1][0] / det, K11 = J[0][0] / det;
+  const T dw = (det < 0 ? -det : det) * w;
+  G3[0] = dw * (K00 * K00 + K01 * K01);
+  G3[1] = dw * (K00 * K10 + K01 * K11);
+  G3[2] = dw * (K10 * K10 + K11 * K11);
+  return dw;
+}
+
 } // namespace fus

@@ -128,24 +128,43 @@ enum
 // ---------------------------------------------------------------------------------------------
 // Per-element inputs fetched from HBM one round ahead of their use (software pipeline):
 // local dof indices, geometry factors (stiffness) or detJw (mass), cell coefficient.
-template <typename T, int N, int OP, int GEOM>
+// TD = 2 (quadrilaterals; one value per lane, geometry [elem][3][N^2] / detJw [elem][N^2]) keeps
+// its three factors in g2.
+template <typename T, int N, int OP, int GEOM, int TD = 3>
 struct ElemIn
 {
   typedef typename GLoad<T, N>::type GV;
   static constexpr int NV = GLoad<T, N>::NV;
   int er;
-  GV g[(OP == OP_STIFFNESS && GEOM == GEOM_STREAM) ? NV : 1];
-  T dj[(OP == OP_MASS && GEOM == GEOM_STREAM) ? N : 1];
+  GV g[(TD == 3 && OP == OP_STIFFNESS && GEOM == GEOM_STREAM) ? NV : 1];
+  T dj[(TD == 3 && OP == OP_MASS && GEOM == GEOM_STREAM) ? N : 1];
+  T g2[(TD == 2) ? 3 : 1];
 };
 
-template <typename T, int N, int OP, int GEOM>
-__device__ __forceinline__ void elem_fetch(ElemIn<T, N, OP, GEOM>& in, int er,
+template <typename T, int N, int OP, int GEOM, int TD>
+__device__ __forceinline__ void elem_fetch(ElemIn<T, N, OP, GEOM, TD>& in, int er,
                                            const T* __restrict__ geo, int elem_off, int p)
 {
-  constexpr int N2 = N * N, Nd = N * N * N;
+  constexpr int N2 = N * N, Nd = (TD == 3) ? N * N * N : N * N;
   constexpr int VW = GLoad<T, N>::VW, NV = GLoad<T, N>::NV;
   typedef typename GLoad<T, N>::type GV;
   in.er = er;
+  if constexpr (TD == 2)
+  {
+    if (er >= 0)
+    {
+      const int64_t e = elem_off + er;
+      if (OP == OP_STIFFNESS)
+      {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+          in.g2[k] = geo[e * (3 * Nd) + k * Nd + p];
+      }
+      else
+        in.g2[0] = geo[e * Nd + p];
+    }
+    return;
+  }
   if (GEOM == GEOM_STREAM && er >= 0)
   {
     const int64_t e = elem_off + er;
@@ -172,6 +191,64 @@ __device__ __forceinline__ void elem_fetch(ElemIn<T, N, OP, GEOM>& in, int er,
 // One element's operator action, accumulated into the block's LDS vector y_l.
 // ATOMIC: the accumulation is an LDS floating-point atomic (ds_add_f64 / ds_add_f32), so waves need
 // not proceed in conflict-free rounds; otherwise a plain read-modify-write (deterministic).
+// One quadrilateral element (TD = 2): lane p = (b, c) holds the single value at tensor node (b, c);
+// both derivative directions exchange through the element's LDS tile
+// (cpp/fenicsx-sf-naive/common/spectral_op.hpp:273-323 with the transform of :195-207; G = (xx, xy,
+// yy) with xx pairing with the derivative along tensor index 0).
+template <typename T, int N, int OP, int ATOMIC, int NF>
+__device__ __forceinline__ void elem_compute2d(const ElemIn<T, N, OP, GEOM_STREAM, 2>& in,
+                                               const T (&Drb)[N], const T (&Drc)[N],
+                                               const T (&Dcb)[N], const T (&Dcc)[N],
+                                               const T* __restrict__ x_l, T* __restrict__ y_l,
+                                               T* __restrict__ sA,
+                                               const uint16_t* __restrict__ ldm_l,
+                                               const T* __restrict__ cf_l,
+                                               const T* __restrict__ x2_l,
+                                               const T* __restrict__ cf2_l, int p, int b, int c)
+{
+  constexpr int Nd = N * N;
+  if (in.er < 0)
+    return;
+  const int li = ldm_l[in.er * Nd + p];
+  const T cf = (NF == 2) ? T(1) : cf_l[in.er];
+  T Y;
+  if (OP == OP_STIFFNESS)
+  {
+    const T X = (NF == 2) ? cf_l[in.er] * x_l[li] + cf2_l[in.er] * x2_l[li] : x_l[li];
+    sA[p] = X;
+    FUS_WAVE_SYNC();
+    T d0 = T(0), d1 = T(0);
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+    {
+      d0 += Drb[j] * sA[j * N + c];
+      d1 += Drc[j] * sA[b * N + j];
+    }
+    const T F0 = cf * (in.g2[0] * d0 + in.g2[1] * d1);
+    const T F1 = cf * (in.g2[1] * d0 + in.g2[2] * d1);
+    FUS_WAVE_SYNC();
+    sA[p] = F0;
+    FUS_WAVE_SYNC();
+    T acc = T(0);
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      acc += Dcb[j] * sA[j * N + c];
+    FUS_WAVE_SYNC();
+    sA[p] = F1;
+    FUS_WAVE_SYNC();
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      acc += Dcc[j] * sA[b * N + j];
+    Y = acc;
+  }
+  else
+    Y = cf * x_l[li] * in.g2[0];
+  if (ATOMIC)
+    __hip_atomic_fetch_add(&y_l[li], Y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else
+    y_l[li] += Y;
+}
+
 template <typename T, int N, int OP, int ATOMIC, int NF, int GEOM>
 __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, const DTab<T, N>& Dk,
                                              const T (&Drb)[N], const T (&Drc)[N], const T (&Dcb)[N],
@@ -340,13 +417,15 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 // Launch bound: up to 8 waves per workgroup for P <= 4; the higher degrees keep more of the element
 // in registers (beyond 256 per lane) and are limited to 4 waves so one wave per SIMD may use the
 // whole 512-entry register file.
-template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM>
+// TD = 2: the same block machinery for quadrilateral elements (Nd = N^2, GEOM_STREAM only).
+template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3>
 __global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P <= 4 && GEOM == GEOM_AFFINE) ? 4 : 1)
 k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
            const T* __restrict__ geo, const T* __restrict__ coef, const T* __restrict__ x,
            T* __restrict__ bvec, T* __restrict__ partial, const StageArgs<T> S)
 {
-  constexpr int N = P + 1, N2 = N * N, Nd = N * N * N;
+  static_assert(TD == 3 || GEOM == GEOM_STREAM, "quadrilaterals use the streamed geometry");
+  constexpr int N = P + 1, N2 = N * N, Nd = (TD == 3) ? N * N * N : N * N;
   constexpr int EPW = (64 / N2) > 0 ? (64 / N2) : 1;
 
   extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -388,12 +467,12 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   };
 
   // first trip's geometry is requested before the block's dof values are staged
-  ElemIn<T, N, OP, GEOM> inA, inB;
+  ElemIn<T, N, OP, GEOM, TD> inA, inB;
   {
     int e0 = -1;
     if (active && ntrips > 0)
       e0 = ATOMIC ? (myslot < sh.nelem ? myslot : -1) : (int)A.rounds[sh.rounds_off + myslot];
-    elem_fetch<T, N, OP, GEOM>(inA, e0, geo, elem_off, p);
+    elem_fetch<T, N, OP, GEOM, TD>(inA, e0, geo, elem_off, p);
   }
 
   // ---- prologue: stage the block's dof values in LDS, clear the accumulator; all loads of a
@@ -509,21 +588,32 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     w3[a] = (GEOM == GEOM_AFFINE) ? w_l[a] * w_l[b] * w_l[c] : T(0);
 
   // ---- trips, two per iteration: while one register set is consumed the other is in flight ----
+#define FUS_ELEM_COMPUTE(in)                                                                       \
+  do                                                                                               \
+  {                                                                                                \
+    if constexpr (TD == 3)                                                                         \
+      elem_compute<T, N, OP, ATOMIC, NF, GEOM>(in, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB,       \
+                                               ldm_l, cf_l, x2_l, cf2_l, gc_l, w3, p, b, c);       \
+    else                                                                                           \
+      elem_compute2d<T, N, OP, ATOMIC, NF>(in, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, ldm_l, cf_l,      \
+                                           x2_l, cf2_l, p, b, c);                                  \
+  } while (0)
   for (int r = 0; r < ntrips; r += 2)
   {
     const bool has1 = r + 1 < ntrips;
-    elem_fetch<T, N, OP, GEOM>(inB, elem_of(r + 1), geo, elem_off, p);
-    elem_compute<T, N, OP, ATOMIC, NF, GEOM>(inA, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, x2_l, cf2_l, gc_l, w3, p, b, c);
+    elem_fetch<T, N, OP, GEOM, TD>(inB, elem_of(r + 1), geo, elem_off, p);
+    FUS_ELEM_COMPUTE(inA);
     if (!ATOMIC && A.waves > 1)
       __syncthreads();
-    elem_fetch<T, N, OP, GEOM>(inA, elem_of(r + 2), geo, elem_off, p);
+    elem_fetch<T, N, OP, GEOM, TD>(inA, elem_of(r + 2), geo, elem_off, p);
     if (has1)
     {
-      elem_compute<T, N, OP, ATOMIC, NF, GEOM>(inB, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB, ldm_l, cf_l, x2_l, cf2_l, gc_l, w3, p, b, c);
+      FUS_ELEM_COMPUTE(inB);
       if (!ATOMIC && A.waves > 1)
         __syncthreads();
     }
   }
+#undef FUS_ELEM_COMPUTE
   __syncthreads();
 
   // ---- epilogue: each dof written once ----
@@ -864,6 +954,54 @@ __global__ void k_geometry_affine(int64_t ncells, const int32_t* __restrict__ ce
   Gc[e * 7 + 6] = dw;
   const float rel = (float)sqrt((double)(err2 / h2));
   atomicMax(affine_err_bits, __float_as_uint(rel));  // non-negative floats order like their bits
+}
+
+// Quadrilateral cells: G[e][3][N^2] (xx, xy, yy planes) and detJw[e][N^2] for internal element e
+// (cpp/fenicsx-sf-naive/common/precompute.hpp; bilinear geometry, first two coordinates).
+template <typename T, int N>
+__global__ void k_geometry2d(int64_t ncells, const int32_t* __restrict__ cell_perm,
+                             const T* __restrict__ xg, const int32_t* __restrict__ xdofmap,
+                             const double* __restrict__ pts, const double* __restrict__ wts,
+                             T* __restrict__ G, T* __restrict__ detJ)
+{
+  constexpr int Nd = N * N;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= ncells * Nd)
+    return;
+  const int64_t e = gid / Nd;
+  const int q = (int)(gid - e * Nd);
+  const int bb = q / N, cc = q - bb * N;
+  const int64_t cell = cell_perm[e];
+  T cd[4][3];
+  for (int v = 0; v < 4; ++v)
+    for (int j = 0; j < 3; ++j)
+      cd[v][j] = xg[3 * (int64_t)xdofmap[cell * 4 + v] + j];
+  T J[2][2], G3[3];
+  jacobian2<T>(cd, pts[bb], pts[cc], J);
+  const T dw = geometric_factor2<T>(J, (T)(wts[bb] * wts[cc]), G3);
+  detJ[e * Nd + q] = dw;
+  for (int gi = 0; gi < 3; ++gi)
+    G[e * (3 * Nd) + gi * Nd + q] = G3[gi];
+}
+
+// internal layout -> reference layout G[cell][point][3], detJ[cell][point]
+template <typename T, int N>
+__global__ void k_geometry_export2d(int64_t ncells, const int32_t* __restrict__ cell_perm,
+                                    const T* __restrict__ G, const T* __restrict__ detJ,
+                                    T* __restrict__ Gout, T* __restrict__ dout)
+{
+  constexpr int Nd = N * N;
+  const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= ncells * Nd)
+    return;
+  const int64_t e = gid / Nd;
+  const int q = (int)(gid - e * Nd);
+  const int64_t cell = cell_perm[e];
+  if (dout)
+    dout[cell * Nd + q] = detJ[e * Nd + q];
+  if (Gout)
+    for (int gi = 0; gi < 3; ++gi)
+      Gout[(cell * Nd + q) * 3 + gi] = G[e * (3 * Nd) + gi * Nd + q];
 }
 
 // internal streaming layout -> reference layout G[cell][point][6], detJ[cell][point]

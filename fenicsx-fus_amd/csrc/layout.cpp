@@ -55,14 +55,16 @@ struct Rcb
 
 std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
                          const int32_t* dm, const double* centroids, int block_elems, int waves,
-                         const uint8_t* force_shared)
+                         const uint8_t* force_shared, int tdim)
 {
   if (P < 1 || P > 15)
     return "unsupported degree";
+  if (tdim != 2 && tdim != 3)
+    return "unsupported topological dimension";
   if (ncells <= 0 || ndofs <= 0)
     return "empty mesh";
   L = Layout();
-  L.P = P, L.N = P + 1, L.Nd = L.N * L.N * L.N;
+  L.P = P, L.N = P + 1, L.tdim = tdim, L.Nd = tdim == 3 ? L.N * L.N * L.N : L.N * L.N;
   L.ncells = ncells, L.ndofs = ndofs;
   L.waves = std::max(1, waves);
   L.epw = std::max(1, 64 / (L.N * L.N));

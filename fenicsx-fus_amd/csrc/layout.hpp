@@ -18,7 +18,8 @@ namespace fus
 
 struct Layout
 {
-  int P = 0, N = 0, Nd = 0;
+  int P = 0, N = 0, Nd = 0;  // Nd = N^tdim nodes per element
+  int tdim = 3;
   int waves = 4;   // waves per workgroup
   int epw = 1;     // elements per wave = 64 / N^2 (at least 1)
   int slots = 4;   // elements per round = waves * epw
@@ -70,13 +71,13 @@ struct Layout
   }
 };
 
-// Builds the layout.  centroids: [ncells*3] (any consistent coordinates; used by the recursive
+// Builds the layout.  centroids: [ncells*3] (any consistent coordinates, z = 0 for quadrilaterals; used by the recursive
 // coordinate bisection that forms compact blocks).  force_shared (optional, [ndofs]): dofs that must
 // be classified shared even if a single local block touches them (dofs held by other ranks too).
 // Returns empty string or an error message.
 std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
                          const int32_t* tensor_dofmap, const double* centroids, int block_elems,
-                         int waves, const uint8_t* force_shared = nullptr);
+                         int waves, const uint8_t* force_shared = nullptr, int tdim = 3);
 
 // Internal consistency check used by fus_layout_check and the CPU tests.
 std::string verify_layout(const Layout& L, const int32_t* tensor_dofmap);

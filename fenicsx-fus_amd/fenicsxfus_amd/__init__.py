@@ -8,5 +8,6 @@ from .mesh import BoxMesh, CellFunction, FacetTags, Function, FunctionSpace, tag
 from .models import (LinearSpectralExplicit, LossySpectralExplicit, WesterveltSpectralExplicit,  # noqa: F401
                      compute_diffusivity_of_sound,
                      group_finish_setup, group_rk4_steps)
-from .operators import MassSpectral3D, SpectralOperatorData, StiffnessSpectral3D  # noqa: F401
-from .unstructured import HexFunctionSpace, HexMesh, read_xdmf_hex_mesh  # noqa: F401,E402
+from .operators import (MassSpectral2D, MassSpectral3D, SpectralOperatorData, StiffnessSpectral2D,  # noqa: F401
+                        StiffnessSpectral3D)
+from .unstructured import HexFunctionSpace, HexMesh, QuadMesh, read_xdmf_hex_mesh, read_xdmf_mesh  # noqa: F401,E402

@@ -49,7 +49,7 @@ class SpectralOperatorData:
         self.ncells = gdm.shape[0]
         self.ndofs = V.dofmap.index_map.size_local + V.dofmap.index_map.num_ghosts
         self.h = C.c_void_p()
-        tdim = mesh.topology.dim
+        tdim = self.tdim = mesh.topology.dim
         order = 1 if gdm.shape[1] == (1 << tdim) else 2
         self.ctx.set_option("fields", fields)   # LDS sizing: 2 operator inputs for the lossy model
         try:
@@ -82,8 +82,8 @@ class SpectralOperatorData:
         return self._apply(lib().fus_mass_apply, x, coeffs, y)
 
     def geometry(self):
-        Nd = (self.P + 1) ** 3
-        G = np.empty((self.ncells, Nd, 6), dtype=self.dtype)
+        Nd = (self.P + 1) ** self.tdim
+        G = np.empty((self.ncells, Nd, 6 if self.tdim == 3 else 3), dtype=self.dtype)
         dJ = np.empty((self.ncells, Nd), dtype=self.dtype)
         check(lib().fus_op_get_geometry(self.h, ptr(G), ptr(dJ)))
         return G, dJ
@@ -137,3 +137,20 @@ class MassSpectral3D:
 
     def __call__(self, x, coeffs, y):
         return self.data.mass(x, coeffs, y)
+
+
+class StiffnessSpectral2D(StiffnessSpectral3D):
+    """``StiffnessSpectral2D<T,P>(V)`` on quadrilaterals
+    (cpp/fenicsx-sf-naive/common/spectral_op.hpp:226-359); same call convention."""
+
+    def __init__(self, V, data: SpectralOperatorData | None = None, ctx: Context | None = None):
+        super().__init__(V, data, ctx)
+        assert self.data.tdim == 2
+
+
+class MassSpectral2D(MassSpectral3D):
+    """``MassSpectral2D<T,P>(V)`` on quadrilaterals (cpp/fenicsx-sf-naive/common/spectral_op.hpp:29-107)."""
+
+    def __init__(self, V, data: SpectralOperatorData | None = None, ctx: Context | None = None):
+        super().__init__(V, data, ctx)
+        assert self.data.tdim == 2

@@ -1,14 +1,15 @@
-"""Unstructured hexahedral meshes: XDMF/HDF5 ingestion and the degree-P GLL function space on
-them.
+"""Unstructured hexahedral / quadrilateral meshes: XDMF/HDF5 ingestion and the degree-P GLL function
+space on them.
 
 The reference reads Gmsh meshes through DOLFINx (``XDMFFile::read_mesh`` + ``read_meshtags``,
 cpp/fenicsx-sf/benchmarks/PH1/BM7-SC1/main.cpp:55-64) and lets DOLFINx/Basix number the DOFs.
 Here the same files are read with :mod:`hdf5_lite`, cells are brought from XDMF/VTK vertex order to
 the tensor order libfusmi uses (v = vx + 2 vy + 4 vz), and the conforming tensor-product dofmap is
-built geometrically: every element node is mapped to physical space with the trilinear map and
+built geometrically: every element node is mapped to physical space with the tri-/bilinear map and
 nodes that coincide are one DOF (GLL nodes on a shared face/edge coincide from both sides because
 the map restricted to the shared entity is the same).  The count is checked against the
-topological formula  #V + #E (P-1) + #F (P-1)^2 + #C (P-1)^3.
+topological formula  #V + #E (P-1) + #F (P-1)^2 + #C (P-1)^3  (quadrilaterals: #V + #E (P-1) +
+#C (P-1)^2; the reference's 2-D fixtures are cpp/fenicsx-sf-naive/tests/test_operators2d/mesh_1).
 """
 from __future__ import annotations
 
@@ -29,18 +30,29 @@ FACET_VERTS = np.array([[0, 1, 2, 3], [0, 1, 4, 5], [0, 2, 4, 6], [1, 3, 5, 7], 
 _EDGES = np.array([[0, 1], [2, 3], [4, 5], [6, 7], [0, 2], [1, 3], [4, 6], [5, 7], [0, 4], [1, 5], [2, 6], [3, 7]])
 
 
+# quadrilaterals: XDMF/VTK order is counter-clockwise; tensor v = vx + 2 vy.  DOLFINx local facets
+# (edges): 0: y=0, 1: x=0, 2: x=1, 3: y=1
+VTK_QUAD_TO_TENSOR = np.array([0, 1, 3, 2])
+QUAD_FACET_VERTS = np.array([[0, 1], [0, 2], [1, 3], [2, 3]])
+
+
 class HexMesh:
     """Unstructured first-order hexahedral mesh with the attributes the adapter reads from a
     DOLFINx mesh (``geometry.x``, ``geometry.dofmap``, ``topology.dim``, ``index_map``)."""
 
+    tdim = 3
+    _facet_verts = FACET_VERTS
+    _edges = _EDGES
+
     def __init__(self, x, cells, dtype=np.float64):
         x = np.ascontiguousarray(x, dtype=np.float64)
+        if x.shape[1] == 2:                                            # XDMF "XY" geometry
+            x = np.hstack([x, np.zeros((x.shape[0], 1))])
         cells = np.ascontiguousarray(cells, dtype=np.int32)
-        assert x.shape[1] == 3 and cells.shape[1] == 8
-        self.tdim = 3
+        assert x.shape[1] == 3 and cells.shape[1] == (1 << self.tdim)
         self.dtype = np.dtype(dtype)
         self.geometry = _Geometry(x.astype(self.dtype), cells, 3)
-        self.topology = _Topology(3, cells.shape[0], cells.shape[0])
+        self.topology = _Topology(self.tdim, cells.shape[0], cells.shape[0])
         self._x64 = x
 
     @property
@@ -51,21 +63,22 @@ class HexMesh:
         return self._x64[self.geometry.dofmap].mean(axis=1)
 
     def _facet_keys(self):
-        fv = self.geometry.dofmap[:, FACET_VERTS]                     # [nc, 6, 4]
-        return np.sort(fv, axis=2).reshape(-1, 4)
+        fv = self.geometry.dofmap[:, self._facet_verts]               # [nc, nfacets, nverts]
+        return np.sort(fv, axis=2).reshape(-1, self._facet_verts.shape[1])
 
     def exterior_facets(self):
-        """(cells, local facets) of the faces that belong to exactly one cell."""
+        """(cells, local facets) of the facets that belong to exactly one cell."""
         keys = self._facet_keys()
+        nf = self._facet_verts.shape[0]
         _, inv, cnt = np.unique(keys, axis=0, return_inverse=True, return_counts=True)
         ext = np.nonzero(cnt[inv.ravel()] == 1)[0]
-        return (ext // 6).astype(np.int32), (ext % 6).astype(np.int32)
+        return (ext // nf).astype(np.int32), (ext % nf).astype(np.int32)
 
     def facet_tags(self, facet_vertices, values) -> FacetTags:
-        """Tags given per facet as 4 vertex ids (XDMF ``MeshTags`` topology) -> (cell, local facet)
+        """Tags given per facet as vertex ids (XDMF ``MeshTags`` topology) -> (cell, local facet)
         pairs; only exterior facets are kept (the forms integrate over ``ds``)."""
         cells, lf = self.exterior_facets()
-        keys = np.sort(self.geometry.dofmap[cells][np.arange(len(cells))[:, None], FACET_VERTS[lf]], axis=1)
+        keys = np.sort(self.geometry.dofmap[cells][np.arange(len(cells))[:, None], self._facet_verts[lf]], axis=1)
         lut = {tuple(k): i for i, k in enumerate(keys)}
         fc, fl, fv = [], [], []
         for verts, val in zip(np.sort(np.asarray(facet_vertices), axis=1), np.asarray(values).ravel()):
@@ -75,31 +88,40 @@ class HexMesh:
         return FacetTags(np.array(fc, np.int32), np.array(fl, np.int32), np.array(fv, np.int32))
 
     def entity_counts(self):
-        """(#vertices used, #edges, #faces, #cells)."""
+        """(#vertices used, #edges, #faces, #cells); a quadrilateral mesh has no faces besides its cells."""
         dm = self.geometry.dofmap
         nv = len(np.unique(dm))
-        ne = len(np.unique(np.sort(dm[:, _EDGES].reshape(-1, 2), axis=1), axis=0))
-        nf = len(np.unique(self._facet_keys(), axis=0))
+        ne = len(np.unique(np.sort(dm[:, self._edges].reshape(-1, 2), axis=1), axis=0))
+        nf = len(np.unique(self._facet_keys(), axis=0)) if self.tdim == 3 else 0
         return nv, ne, nf, dm.shape[0]
 
 
+class QuadMesh(HexMesh):
+    """Unstructured first-order quadrilateral mesh (vertices in tensor order v = vx + 2 vy)."""
+
+    tdim = 2
+    _facet_verts = QUAD_FACET_VERTS
+    _edges = QUAD_FACET_VERTS
+
+
 class HexFunctionSpace:
-    """Degree-P GLL Lagrange space on a :class:`HexMesh`; ``tensor_dofmap`` in tensor order like
-    ``reorder_dofmap`` produces (cpp/fenicsx-sf/common/permute.hpp:15-42)."""
+    """Degree-P GLL Lagrange space on a :class:`HexMesh` or :class:`QuadMesh`; ``tensor_dofmap`` in
+    tensor order like ``reorder_dofmap`` produces (cpp/fenicsx-sf/common/permute.hpp:15-42)."""
 
     def __init__(self, mesh: HexMesh, P: int, tol: float = 1e-9):
         self.mesh, self.P = mesh, int(P)
         N = P + 1
+        t = mesh.tdim
         pts, _ = tables.gll(N)
         self.nodes1d = pts
         x = mesh._x64
-        cd = x[mesh.geometry.dofmap]                                   # [nc, 8, 3]
-        # trilinear shape functions at the N^3 tensor nodes, tensor index (i0*N + i1)*N + i2
-        i0, i1, i2 = np.meshgrid(pts, pts, pts, indexing="ij")
-        X = np.stack([i0.ravel(), i1.ravel(), i2.ravel()], axis=1)     # [Nd, 3]
-        phi = np.ones((X.shape[0], 8))
-        for v in range(8):
-            for d in range(3):
+        cd = x[mesh.geometry.dofmap]                                   # [nc, 2^t, 3]
+        # multilinear shape functions at the N^t tensor nodes, tensor index (i0*N + i1)*N + i2
+        grids = np.meshgrid(*([pts] * t), indexing="ij")
+        X = np.stack([g.ravel() for g in grids], axis=1)               # [Nd, t]
+        phi = np.ones((X.shape[0], 1 << t))
+        for v in range(1 << t):
+            for d in range(t):
                 phi[:, v] *= X[:, d] if (v >> d) & 1 else 1.0 - X[:, d]
         nodes = np.einsum("qv,cvk->cqk", phi, cd)                      # [nc, Nd, 3]
         self._node_x = nodes
@@ -108,7 +130,7 @@ class HexFunctionSpace:
         _, first, inv = np.unique(q, axis=0, return_index=True, return_inverse=True)
         ndofs = len(first)
         nv, ne, nf, nc = mesh.entity_counts()
-        expect = nv + ne * (P - 1) + nf * (P - 1) ** 2 + nc * (P - 1) ** 3
+        expect = nv + ne * (P - 1) + nf * (P - 1) ** 2 + nc * (P - 1) ** t
         if ndofs != expect:
             raise ValueError(f"geometric dof matching found {ndofs} dofs, topology says {expect}")
         self.tensor_dofmap = np.ascontiguousarray(inv.reshape(nodes.shape[0], -1), dtype=np.int32)
@@ -124,9 +146,10 @@ class HexFunctionSpace:
         return self._dof_x.copy()
 
 
-def read_xdmf_hex_mesh(xdmf_path: str, name: str | None = None, dtype=np.float64):
+def read_xdmf_mesh(xdmf_path: str, name: str | None = None, dtype=np.float64):
     """Read ``<Grid Name=name>`` (default: the first grid) of an XDMF file written by DOLFINx/meshio
-    and its cell / facet mesh tags if present.  Returns (HexMesh, cell_values | None, FacetTags | None)."""
+    and its cell / facet mesh tags if present.  Returns (HexMesh | QuadMesh, cell_values | None,
+    FacetTags | None)."""
     root = ET.parse(xdmf_path).getroot()
     base = os.path.dirname(os.path.abspath(xdmf_path))
     grids = {g.get("Name"): g for g in root.iter("Grid")}
@@ -141,11 +164,14 @@ def read_xdmf_hex_mesh(xdmf_path: str, name: str | None = None, dtype=np.float64
         return files[fname][dset]
 
     topo = grid.find("Topology")
-    if topo.get("TopologyType").lower() != "hexahedron" or topo.get("NodesPerElement", "8") != "8":
-        raise NotImplementedError("only first-order hexahedral grids are read")
-    cells = data(topo.find("DataItem"))[:, VTK_TO_TENSOR]
+    kind = topo.get("TopologyType").lower()
     x = data(grid.find("Geometry").find("DataItem"))
-    mesh = HexMesh(x, cells, dtype=dtype)
+    if kind == "hexahedron" and topo.get("NodesPerElement", "8") == "8":
+        mesh = HexMesh(x, data(topo.find("DataItem"))[:, VTK_TO_TENSOR], dtype=dtype)
+    elif kind == "quadrilateral" and topo.get("NodesPerElement", "4") == "4":
+        mesh = QuadMesh(x, data(topo.find("DataItem"))[:, VTK_QUAD_TO_TENSOR], dtype=dtype)
+    else:
+        raise NotImplementedError("only first-order hexahedral and quadrilateral grids are read")
     cell_vals, ftags = None, None
     g = grids.get(f"{name}_cells")
     if g is not None:
@@ -156,3 +182,6 @@ def read_xdmf_hex_mesh(xdmf_path: str, name: str | None = None, dtype=np.float64
         fvals = data(g.find("Attribute").find("DataItem")).ravel()
         ftags = mesh.facet_tags(fverts, fvals)
     return mesh, cell_vals, ftags
+
+
+read_xdmf_hex_mesh = read_xdmf_mesh

@@ -82,10 +82,13 @@ int fus_comm_init_local(fus_ctx** ctxs, int n);
  * the device the scaled geometric factors G = J^-1 J^-T |detJ| w and |detJ| w
  * (compute_scaled_geometrical_factor / _jacobian_determinant, precompute.hpp:101-213, 33-94).
  * One object serves both operators (the reference builds one per operator, Lossy.hpp:152-153).
- *   tdim        3 (hexahedra).  2-D (quadrilaterals, fenicsx-sf-naive) is not offloaded.
+ *   tdim        3 (hexahedra) or 2 (quadrilaterals: StiffnessSpectral2D / MassSpectral2D,
+ *               cpp/fenicsx-sf-naive/common/spectral_op.hpp:29-107, 226-359; N^2 nodes per cell,
+ *               geom_dofmap int32[ncells * 4] with v = vx + 2vy, geom_order 1 only, G has 3 entries
+ *               (xx, xy, yy) per point, local facets 0..3 = y=0, x=0, x=1, y=1)
  *   P           polynomial degree 2..7; N = P+1 nodes per direction
  *   dtype       FUS_F64 | FUS_F32: type of geom_x and of every vector/coefficient argument later
- *   tensor_dofmap  int32[ncells * N^3], local DOF indices < ndofs, x-slowest tensor order
+ *   tensor_dofmap  int32[ncells * N^tdim], local DOF indices < ndofs, x-slowest tensor order
  *   nodes1d     double[N]
  *   geom_x      T[nnodes * 3]
  *   geom_order  1: geom_dofmap int32[ncells * 8], vertex order v = vx + 2vy + 4vz (DOLFINx's);

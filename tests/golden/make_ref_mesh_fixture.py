@@ -24,3 +24,17 @@ np.savez_compressed(
     facet_values=f["/MeshTags/hex_facets/Values"].ravel().astype(np.int32),
 )
 print("wrote ref_test_operators3d_mesh.npz")
+
+# The naive 2-D operator test's mesh (cpp/fenicsx-sf-naive/tests/test_operators2d/mesh_1: 265 Gmsh
+# quadrilaterals of the unit square, read by main.cpp:46-53), again data only.
+src2 = "/root/reference/cpp/fenicsx-sf-naive/tests/test_operators2d/mesh_1/mesh.h5"
+f2 = H5File(src2)
+np.savez_compressed(
+    os.path.join(HERE, "ref_test_operators2d_mesh.npz"),
+    geometry=f2["/Mesh/quad/geometry"],
+    topology_vtk=f2["/Mesh/quad/topology"].astype(np.int32),
+    cell_values=f2["/MeshTags/quad_cells/Values"].ravel().astype(np.int32),
+    facet_topology=f2["/MeshTags/quad_facets/topology"].astype(np.int32),
+    facet_values=f2["/MeshTags/quad_facets/Values"].ravel().astype(np.int32),
+)
+print("wrote ref_test_operators2d_mesh.npz")

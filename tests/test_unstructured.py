@@ -125,3 +125,97 @@ def test_point_evaluation(ref_mesh):
     cell, _ = locate(mesh, pts)
     assert (cell >= 0).all()
     assert np.abs(evaluate(V, u, pts) - np.sin(pts[:, 0]) * np.cos(np.pi * pts[:, 1])).max() < 1e-6
+
+
+# ---- the naive 2-D operator test's own quadrilateral mesh -------------------------------------------
+GOLD2 = os.path.join(os.path.dirname(__file__), "golden", "ref_test_operators2d_mesh.npz")
+REF_XDMF2 = "/root/reference/cpp/fenicsx-sf-naive/tests/test_operators2d/mesh_1/mesh.xdmf"
+
+
+@pytest.fixture(scope="module")
+def ref_mesh2d():
+    from fenicsxfus_amd.unstructured import VTK_QUAD_TO_TENSOR, QuadMesh
+    g = np.load(GOLD2)
+    mesh = QuadMesh(g["geometry"], g["topology_vtk"][:, VTK_QUAD_TO_TENSOR])
+    return mesh, mesh.facet_tags(g["facet_topology"], g["facet_values"])
+
+
+def _recipe2d(V, nc):
+    """Inputs of cpp/fenicsx-sf-naive/tests/test_operators2d/main.cpp:63-104, 107, 154, 202, 249, 296:
+    u = 1, u_n = 2, v_n = cos(x) sin(pi y), w_n = u_n^2, c0 = 1.5, rho0 = 1, delta0 = beta0 = 10;
+    (operator, input, per-cell coefficient) of the five spectral-vs-FFCx comparisons m1, m2, m3, b1, b2."""
+    X = V.tabulate_dof_coordinates()
+    n = V.num_dofs
+    u, un = np.ones(n), np.full(n, 2.0)
+    vn = np.cos(X[:, 0]) * np.sin(np.pi * X[:, 1])
+    c0, rho0, delta0, beta0 = 1.5, 1.0, 10.0, 10.0
+    full = lambda v: np.full(nc, v)  # noqa: E731
+    return [("mass", u, full(1.0 / rho0 / c0 / c0)),
+            ("mass", un, full(-2.0 * beta0 / rho0**2 / c0**4)),
+            ("mass", un * un, full(2.0 * beta0 / rho0**2 / c0**4)),
+            ("stiffness", vn, full(-1.0 / rho0)),
+            ("stiffness", vn, full(-delta0 / rho0 / c0 / c0))]
+
+
+def test_reference_2d_mesh_reader_space_and_oracle_kats(orc, ref_mesh2d):
+    mesh, tags = ref_mesh2d
+    if os.path.exists(REF_XDMF2):
+        m2, cv, t2 = fa.read_xdmf_mesh(REF_XDMF2)
+        assert np.array_equal(m2.geometry.dofmap, mesh.geometry.dofmap) and np.array_equal(m2.geometry.x, mesh.geometry.x)
+        assert len(cv) == 265 and np.array_equal(t2.cells, tags.cells)
+    assert mesh.tdim == 2 and mesh.num_cells == 265 and mesh.entity_counts() == (296, 560, 0, 265)
+    assert len(tags.cells) == 60                                 # every boundary edge is tagged
+    V = HexFunctionSpace(mesh, 4)
+    assert V.num_dofs == 296 + 3 * 560 + 9 * 265
+    wts, D = orc.gll_weights_at(V.nodes1d), orc.dphi(V.nodes1d)
+    G, dJ = orc.geometry(2, mesh.geometry.x, mesh.geometry.dofmap, V.nodes1d, wts)
+    assert abs(dJ.sum() - 1.0) < 1e-13                           # unit square
+    n, nc = V.num_dofs, mesh.num_cells
+    ops = _recipe2d(V, nc)
+    # known answers of the recipe: m1 sums to area / (rho c^2); K(const) = 0; energy of v_n
+    m1 = orc.mass(2, 5, V.tensor_dofmap, dJ, ops[0][2], ops[0][1], np.zeros(n))
+    assert abs(m1.sum() - 1.0 / 2.25) < 1e-13
+    b1 = orc.stiffness(2, 5, V.tensor_dofmap, G, D, ops[3][2], ops[3][1], np.zeros(n))
+    exact = (0.5 - np.sin(2) / 4) * 0.5 + np.pi**2 * (0.5 + np.sin(2) / 4) * 0.5   # int |grad v_n|^2
+    assert abs(-(ops[3][1] @ b1) - exact) < 1e-8 * exact
+    perim = orc.facet_diag(2, tags.cells, tags.local_facets, np.ones(nc), mesh.geometry.x, mesh.geometry.dofmap,
+                           V.nodes1d, wts, V.tensor_dofmap, n).sum()
+    assert abs(perim - 4.0) < 1e-12
+
+
+@pytest.mark.gpu
+def test_reference_2d_operator_test_on_its_own_mesh(orc, ref_mesh2d):
+    """The five operator comparisons of cpp/fenicsx-sf-naive/tests/test_operators2d/main.cpp on its
+    Gmsh mesh, HIP vs oracle, then 10 Linear RK4 steps (LinearSpectral2D, naive Linear.hpp:52-350)."""
+    mesh, tags = ref_mesh2d
+    P = 4
+    V = HexFunctionSpace(mesh, P)
+    n, nc = V.num_dofs, mesh.num_cells
+    wts, D = orc.gll_weights_at(V.nodes1d), orc.dphi(V.nodes1d)
+    G, dJ = orc.geometry(2, mesh.geometry.x, mesh.geometry.dofmap, V.nodes1d, wts)
+    ctx = fa.Context(0)
+    d = fa.SpectralOperatorData(V, ctx)
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()  # noqa: E731
+    for kind, x, coef in _recipe2d(V, nc):
+        if kind == "mass":
+            assert rel(fa.MassSpectral2D(V, d)(x, coef, np.zeros(n)),
+                       orc.mass(2, P + 1, V.tensor_dofmap, dJ, coef, x, np.zeros(n))) < 1e-14
+        else:
+            assert rel(fa.StiffnessSpectral2D(V, d)(x, coef, np.zeros(n)),
+                       orc.stiffness(2, P + 1, V.tensor_dofmap, G, D, coef, x, np.zeros(n))) < 1e-12
+    d.close()
+    c, rho = np.full(nc, 1500.0), np.full(nc, 1000.0)
+    m = orc.mass(2, P + 1, V.tensor_dofmap, dJ, 1 / (rho * c * c), np.ones(n), np.zeros(n))
+    src = orc.facet_diag(2, tags.cells, tags.local_facets, 1 / rho, mesh.geometry.x, mesh.geometry.dofmap, V.nodes1d,
+                         wts, V.tensor_dofmap, n)
+    hmin = np.sqrt(dJ.reshape(nc, -1).sum(axis=1)).min()
+    dt = 0.2 * hmin / (1500.0 * P**2)
+    uo, vo = np.zeros(n), np.zeros(n)
+    orc.linear_rk4(2, P + 1, V.tensor_dofmap, G, D, -1 / rho, m, src, np.zeros(n), 5e3, 6e4, 1500.0, 0.0,
+                   10 * dt * (1 - 1e-9), dt, uo, vo)
+    model = fa.LinearSpectralExplicit(mesh, tags, P, c, rho, 5e3, 6e4, 1500.0, 4, dt, V=V, ctx=ctx)
+    model.init()
+    un, vn, _ = model.rk(0.0, 10 * dt * (1 - 1e-9))
+    assert np.abs(uo).max() > 0 and rel(un.x.array, uo) < 1e-10 and rel(vn.x.array, vo) < 1e-10
+    model.close()
+    ctx.close()

@@ -256,7 +256,7 @@ def main():
                                      "general (G streamed, B_general)", "value": v2, "unit": "DOF-updates/s",
                                      "ms_per_step": 1e3 * e2 / args.steps, "algorithmic_bytes_per_dof_update": b2,
                                      "frac_of_8TBps": b2 * v2 / world / 8e12, "finite_nonzero_solution": fin2}
-        if not args.no_cpu and args.dtype == "f64":
+        if not args.no_cpu and args.dtype == "f64" and world == 1:   # CPU leg on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(P, args.cpu_n, args.cpu_steps)
         print(json.dumps(out))
     if world > 1 or launched:

@@ -133,3 +133,85 @@ def test_config1_full_size(orc, ctx):
     assert model.nsteps == 5 and np.abs(u).max() > 0
     assert relmax(un.x.array, u) < TOL_RK and relmax(vn.x.array, v) < TOL_RK
     model.close()
+
+
+def test_quad_lossy_and_westervelt_vs_oracle(orc, ctx):
+    """LossySpectral2D / WesterveltSpectral2D (cpp/fenicsx-sf-naive/common/Lossy.hpp, Westervelt.hpp):
+    the two-input fused pass and the nonlinear mass terms on quadrilaterals."""
+    L, P, n = 0.012, 4, (10, 8)
+    pr = Problem(orc, n, P, hi=[L, L], perturb=0.1)
+    nc = pr.mesh.num_cells
+    c, rho = np.full(nc, 1500.0), np.full(nc, 1000.0)
+    cx = pr.mesh.cell_centroids()[:, 0]
+    sel = (cx > 0.4 * L) & (cx < 0.6 * L)
+    c[sel], rho[sel] = 2800.0, 1850.0
+    tags = tag_box_boundary(pr.mesh)
+    f0, s0 = 0.5e6, 1500.0
+    w0 = 2 * np.pi * f0
+    delta = np.full(nc, fa.compute_diffusivity_of_sound(w0, 1500.0, 0.2))
+    delta[sel] = fa.compute_diffusivity_of_sound(w0, 2800.0, 400.0 / 20.0 * np.log(10.0))
+    beta = np.where(sel, 6.0, 3.5)
+    dt = 0.5 * (L / n[0]) / (c.max() * P**2)
+    nsteps = 20
+    tf = nsteps * dt * (1 - 1e-9)
+    m, src, absb, src2, lin, att = pr.lossy_model_vectors(c, rho, delta, tags)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    assert orc.lossy_rk4(2, pr.N, pr.dm, pr.G, pr.D, lin, att, m, src, absb, src2, f0, 6e4, s0, 0.0, tf, dt, u, v) == nsteps
+    model = fa.LossySpectralExplicit(pr.mesh, tags, P, c, rho, delta, f0, 6e4, s0, 4, dt, V=pr.V, ctx=ctx)
+    assert relmax(model.mass_vector(), m) < 1e-14
+    model.init()
+    un, vn, _ = model.rk(0.0, tf)
+    assert np.abs(u).max() > 0 and relmax(un.x.array, u) < TOL_RK and relmax(vn.x.array, v) < TOL_RK
+    model.close()
+    n1 = -2.0 * beta / rho**2 / c**4
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    orc.westervelt_rk4(2, pr.N, pr.dm, pr.G, pr.detJ, pr.D, lin, att, n1, -n1, m, src, absb, src2, f0, 6e6, s0,
+                       0.0, tf, dt, u, v)
+    model = fa.WesterveltSpectralExplicit(pr.mesh, tags, P, c, rho, delta, beta, f0, 6e6, s0, 4, dt, V=pr.V, ctx=ctx)
+    model.init()
+    un, vn, _ = model.rk(0.0, tf)
+    assert np.abs(u).max() > 0 and relmax(un.x.array, u) < TOL_RK and relmax(vn.x.array, v) < TOL_RK
+    model.close()
+
+
+@pytest.mark.parametrize("size", [2, 3])
+def test_quad_slabs_in_process(orc, size):
+    """x-slab partition of a quadrilateral mesh over `size` contexts on one GPU (in-process
+    transport): same state as the single-rank oracle, interface lines bit-identical."""
+    L, P, n = [0.024, 0.012], 4, (9, 5)
+    f0, p0, s0, nsteps = 0.5e6, 60000.0, 1500.0, 6
+    pr = Problem(orc, n, P, hi=L, perturb=0.1)
+    nc = pr.mesh.num_cells
+    tags = tag_box_boundary(pr.mesh)
+    c, rho = np.full(nc, 1500.0), np.full(nc, 1000.0)
+    m, src, absb, coeff = pr.linear_model_vectors(c, rho, tags)
+    dt = 0.5 * (L[0] / n[0]) / (1500.0 * P**2)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    orc.linear_rk4(2, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, f0, p0, s0, 0.0, nsteps * dt * (1 + 1e-12), dt, u, v)
+    ctxs = [fa.Context(0) for _ in range(size)]
+    fa.Context.init_local_group(ctxs)
+    models, offs = [], []
+    for r in range(size):
+        mesh = fa.BoxMesh([0, 0], L, n, rank=r, size=size, perturb=0.1)
+        V = fa.FunctionSpace(mesh, P)
+        k = mesh.num_cells
+        models.append(fa.LinearSpectralExplicit(mesh, tag_box_boundary(mesh), P, np.full(k, 1500.0), np.full(k, 1000.0),
+                                                f0, p0, s0, 4, dt, V=V, ctx=ctxs[r]))
+        offs.append(V.global_offset)
+    fa.group_finish_setup(models)
+    for mdl in models:
+        mdl.init()
+    fa.group_rk4_steps(models, 0.0, dt, nsteps)
+    us = []
+    for r, mdl in enumerate(models):
+        k = mdl.data.ndofs
+        ur = mdl.u_sol().x.array
+        us.append(ur)
+        assert np.abs(ur - u[offs[r]:offs[r] + k]).max() < 1e-10 * np.abs(u).max()
+    for r in range(size - 1):
+        line = len(us[r]) - (offs[r + 1] - offs[r])
+        assert np.array_equal(us[r][-line:], us[r + 1][:line])
+    for mdl in models:
+        mdl.close()
+    for cx in ctxs:
+        cx.close()

@@ -56,13 +56,14 @@ def _link(objs, out, verbose):
     subprocess.check_call(cmd)
 
 
-def build(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
-    """dev=True: P=4-only iteration build into abl/libfusmi_dev.so (use with FUSMI_LIB)."""
+def build(force: bool = False, verbose: bool = False, dev: bool = False, name: str = "dev", defines=()) -> str:
+    """dev=True: P=4-only iteration build into abl/libfusmi_<name>.so (use with FUSMI_LIB); extra -D
+    flags select experiment variants (never shipped)."""
     objroot = os.path.join(HERE, "_build")
     if dev:
-        out = os.path.join(HERE, "..", "abl", "libfusmi_dev.so")
+        out = os.path.join(HERE, "..", "abl", f"libfusmi_{name}.so")
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        _link(_compile_units(os.path.join(objroot, "dev"), (4,), ["-DFUS_DEV_BUILD"], verbose), out, verbose)
+        _link(_compile_units(os.path.join(objroot, name), (4,), ["-DFUS_DEV_BUILD", *defines], verbose), out, verbose)
         return out
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
@@ -71,4 +72,6 @@ def build(force: bool = False, verbose: bool = False, dev: bool = False) -> str:
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, dev="--dev" in sys.argv))
+    nm = sys.argv[sys.argv.index("--name") + 1] if "--name" in sys.argv else "dev"
+    print(build(force="--force" in sys.argv, verbose="-q" not in sys.argv, dev="--dev" in sys.argv, name=nm,
+                defines=[a for a in sys.argv if a.startswith("-D")]))

@@ -655,15 +655,15 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
       V2 bv, mi, w, a0, b0, au, av;
       auto ld = [&](const T* ptr) -> V2 {
         V2 r;
-        if (!tail)
-          r = *reinterpret_cast<const V2*>(ptr + o);
+        if (!tail)  // read once per stage: keep these streams out of L2 / MALL
+          r = __builtin_nontemporal_load(reinterpret_cast<const V2*>(ptr + o));
         else
           r[0] = ptr[o], r[1] = T(0);
         return r;
       };
       auto st = [&](T* ptr, V2 val) {
         if (!tail)
-          *reinterpret_cast<V2*>(ptr + o) = val;
+          __builtin_nontemporal_store(val, reinterpret_cast<V2*>(ptr + o));
         else
           ptr[o] = val[0];
       };
@@ -756,6 +756,10 @@ k_shared_stage(int64_t n, const int32_t* __restrict__ sh_ptr, const int32_t* __r
   T acc = T(0);
   for (int32_t k = sh_ptr[s]; k < sh_ptr[s + 1]; ++k)
     acc += partial[sh_pairs[k]];
+  // model vectors are read / written once per stage: non-temporal, so that the partial slab (written
+  // just before by k_block_op) stays cache resident
+#define FUS_LD(p) __builtin_nontemporal_load(&(p)[s])
+#define FUS_ST(p, val) __builtin_nontemporal_store((val), &(p)[s])
   T kv;
   if (mn1)  // Westervelt (see StageArgs): stage inputs u_n, v_n are u0, v0 at stage 0
   {
@@ -763,28 +767,30 @@ k_shared_stage(int64_t n, const int32_t* __restrict__ sh_ptr, const int32_t* __r
     kv = (acc - mn1[s] * vs * vs) / (m0[s] + mn1[s] * us);
   }
   else
-    kv = acc * minv[s];
+    kv = acc * FUS_LD(minv);
   if (STAGE == 0)
   {
-    const T u = u0[s], v = v0[s];
-    u_[s] = v * bdt + u;
-    v_[s] = kv * bdt + v;
-    un[s] = v * adt + u;
-    vn[s] = kv * adt + v;
+    const T u = FUS_LD(u0), v = FUS_LD(v0);
+    FUS_ST(u_, v * bdt + u);
+    FUS_ST(v_, kv * bdt + v);
+    FUS_ST(un, v * adt + u);
+    FUS_ST(vn, kv * adt + v);
   }
   else if (STAGE == 3)
   {
-    u0[s] = vn[s] * bdt + u_[s];
-    v0[s] = kv * bdt + v_[s];
+    FUS_ST(u0, FUS_LD(vn) * bdt + FUS_LD(u_));
+    FUS_ST(v0, kv * bdt + FUS_LD(v_));
   }
   else
   {
-    const T w = vn[s];
-    u_[s] = w * bdt + u_[s];
-    v_[s] = kv * bdt + v_[s];
-    un[s] = w * adt + u0[s];
-    vn[s] = kv * adt + v0[s];
+    const T w = FUS_LD(vn);
+    FUS_ST(u_, w * bdt + FUS_LD(u_));
+    FUS_ST(v_, kv * bdt + FUS_LD(v_));
+    FUS_ST(un, w * adt + FUS_LD(u0));
+    FUS_ST(vn, kv * adt + FUS_LD(v0));
   }
+#undef FUS_LD
+#undef FUS_ST
 }
 
 // Boundary term of shared boundary dofs, written as one more partial (summed last):

@@ -104,6 +104,10 @@ def main():
                     help="stream: per-point G from HBM (reference data path); auto: per-cell factors on affine meshes")
     ap.add_argument("--both-geometries", type=int, default=1,
                     help="also time the other geometry path and report it under 'other_geometry'")
+    ap.add_argument("--halo-loopback", action="store_true",
+                    help="diagnostic: time the middle slab of 3 with its RCCL exchange looped back to this GPU "
+                         "(exchange overhead rehearsal on one GPU; the solution is not the physical one)")
+    ap.add_argument("--no-profile", action="store_true", help="diagnostic: no per-kernel HIP events in the timed region")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=400)
@@ -127,6 +131,11 @@ def main():
 
     ctx = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves, deterministic=args.deterministic, geometry=args.geometry)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run
+    if args.halo_loopback:
+        assert world == 1 and not launched
+        ctx.set_option("halo_loopback", 1)
+        ctx.comm_init(1, 3, fa.Context.unique_id())
+        args.both_geometries = 0
     if world > 1 or launched:
         import torch.distributed as dist
 
@@ -146,7 +155,10 @@ def main():
 
     P, n = args.P, args.cells
     np_dtype = np.float64 if args.dtype == "f64" else np.float32
-    mesh, V, tags, c0, rho0, freq, p0, dt = workload(n, P, rank, world, dtype=np_dtype)
+    if args.halo_loopback:
+        mesh, V, tags, c0, rho0, freq, p0, dt = workload(n, P, 1, 3, dtype=np_dtype)
+    else:
+        mesh, V, tags, c0, rho0, freq, p0, dt = workload(n, P, rank, world, dtype=np_dtype)
     nc = mesh.num_cells
     ndofs_global = V.dofmap.index_map.size_global
 
@@ -159,7 +171,7 @@ def main():
         affine = model.data.is_affine()
         model.rk4_steps(0.0, dt, warmup)
         if profile:
-            context.profile_enable(True)
+            context.profile_enable(2)      # HIP events around the dominant kernel only (see fusmi.h)
         barrier()
         t0 = time.perf_counter()
         model.rk4_steps(warmup * dt, dt, steps, sync=False)
@@ -171,14 +183,23 @@ def main():
             elapsed = float(tt.item())
         prof = {}
         if profile:
-            prof = {k: context.profile_get(k) for k in ("stiffness", "shared", "boundary", "stage", "halo")}
-            context.profile_enable(False)
+            prof = {k: context.profile_get(k) for k in ("stiffness", "stiffness_if")}
+            # per-kernel breakdown of a step: separate, untimed pass with events around every kernel
+            nb = min(steps, 5)
+            context.profile_enable(1)
+            model.rk4_steps((warmup + steps) * dt, dt, nb)
+            context.synchronize()
+            prof["breakdown_ms_per_step"] = {k: context.profile_get(k)[0] / nb for k in
+                                             ("stiffness", "stiffness_if", "shared", "boundary", "stage", "halo")}
+            context.profile_enable(0)
         u = model.u_sol().x.array
         finite = bool(np.isfinite(u).all()) and float(np.abs(u).max()) > 0.0
         model.close()
         return elapsed, prof, info, affine, finite
 
-    elapsed, prof, info, affine, finite = run(ctx, args.steps, args.warmup, True)
+    elapsed, prof, info, affine, finite = run(ctx, args.steps, args.warmup, not args.no_profile)
+    if args.no_profile:
+        prof = {"stiffness": (0.0, 0), "stiffness_if": (0.0, 0), "breakdown_ms_per_step": {}}
     # secondary measurement: the same workload through the other geometry path (the box mesh is
     # affine: "auto" rebuilds G from 7 numbers per cell instead of streaming 6 per point)
     other = None
@@ -205,10 +226,11 @@ def main():
         b_general = 4 * (b_stiff + 12 * s)
         n_int = info["interior_dofs"]
         alg_launch = b_stiff * ndl + 12 * s * n_int
-        k_ms, k_cnt = prof["stiffness"]
+        # N > 1: the stage's block kernel runs as two launches (interface blocks first, then the rest)
+        k_ms, k_cnt = prof["stiffness"][0] + prof["stiffness_if"][0], prof["stiffness"][1]
         avg_ms = k_ms / max(k_cnt, 1)
         achieved = alg_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        value = ndofs_global * args.steps / elapsed
+        value = (ndl if args.halo_loopback else ndofs_global) * args.steps / elapsed
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
         # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01_pmc_traffic.json); only quoted
         # for the configuration those passes were taken on
@@ -235,7 +257,8 @@ def main():
                                      "(BASELINE.json configs[2])" if (n, P, args.dtype) == (128, 7, "f64") else
                                      "(parity/diagnostic configuration)"), "ndofs_global": int(ndofs_global),
                        "cells_per_gpu": int(nc), "geometry": "affine (7 fp64 per cell, B_affine)" if affine else "general (G streamed, 6 fp64 per point, B_general)",
-                       "partition": f"x-slabs x{world}", "blocks": info["nblocks"],
+                       "partition": "middle x-slab of 3, RCCL exchange looped back (diagnostic)" if args.halo_loopback
+                       else f"x-slabs x{world}", "blocks": info["nblocks"],
                        "lds_bytes_per_block": info["lds_bytes"], "dt": dt},
             "roofline": {"bound": "hbm", "kernel": f"k_block_op<{'double' if args.dtype == 'f64' else 'float'},{P},stiffness,+fused RK4 stage>", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
@@ -245,7 +268,7 @@ def main():
             "step_roofline": {"algorithmic_bytes_per_dof_update": b_general,
                               "achieved_GBps": b_general * value / world / 1e9,
                               "frac_of_8TBps": b_general * value / world / 8e12},
-            "kernel_ms_per_step": {k: v[0] / args.steps for k, v in prof.items()},
+            "kernel_ms_per_step": prof["breakdown_ms_per_step"],
             "finite_nonzero_solution": finite,
         }
         if other is not None:

@@ -143,11 +143,17 @@ struct fus_ctx
   // 0 = auto: 32 elements / 4 waves when G is streamed, 16 / 4 on the affine path (measured best
   // on MI355X at p=4 fp64, profiles/r01_block_sweep.txt)
   int block_elems = 0, waves = 0;
-  bool prof = false;
+  int prof = 0;  // 0 off, 1 all scopes, 2 block-operator kernel only
   std::map<std::string, Prof> profs;
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
   bool local_group = false;  // in-process transport (single-GPU rehearsal of the multi-rank path)
+  // timing rehearsal of the RCCL exchange on one GPU (option "halo_loopback"): the context keeps its
+  // logical (rank, nranks) but owns a 1-rank communicator and every send / receive goes to itself,
+  // so a middle slab exercises pack -> ncclSend/ncclRecv -> ordered unpack with realistic launch
+  // and synchronisation cost (the received planes are its own: results are NOT the physical ones)
+  bool loopback = false;
+  bool overlap_blocks = false;  // launch interface blocks first, overlap the exchange with the rest
 };
 
 struct Neigh
@@ -256,7 +262,9 @@ struct ProfScope
   hipEvent_t e0 = nullptr, e1 = nullptr;
   ProfScope(fus_ctx* c_, const char* name) : c(c_)
   {
-    if (c->prof)
+    // level 1: every scope; level 2: the dominant kernel only ("stiffness", "stiffness_if") -- each
+    // event record drains the queue between two kernels, so a timed run keeps them to a minimum
+    if (c->prof == 1 || (c->prof == 2 && !strncmp(name, "stiffness", 9)))
     {
       p = &c->profs[name];
       (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
@@ -278,8 +286,10 @@ struct ProfScope
 // -------------------------------------------------------------------------------------------------
 template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3>
 static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec,
-                             const StageArgs<T>& S)
+                             const StageArgs<T>& S, int blk_begin, int blk_count)
 {
+  if (blk_count <= 0)
+    return FUS_OK;
   constexpr int N = P + 1;
   DTab<T, N> Dk;
   for (int i = 0; i < N * N; ++i)
@@ -291,35 +301,41 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD>), dim3(op->L.nblocks),
-                     dim3(64 * op->L.waves), op->lds_bytes, op->ctx->stream, op->A, Dk,
+  BlockArgs A = op->A;
+  A.blk_begin = blk_begin;
+  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD>), dim3(blk_count),
+                     dim3(64 * op->L.waves), op->lds_bytes, op->ctx->stream, A, Dk,
                      static_cast<const T*>(op->d_Dg), geo, coef, x, bvec,
                      static_cast<T*>(op->d_partial), S);
   HIPCHK(hipGetLastError());
   return FUS_OK;
 }
 
+// Blocks [blk_begin, blk_begin + blk_count) of the layout; blk_count < 0: all blocks.
 template <typename T, int P, int OP, int STAGE, int NF = 1>
 static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec,
-                           const StageArgs<T>& S)
+                           const StageArgs<T>& S, int blk_begin = 0, int blk_count = -1)
 {
   if (NF > op->nfields)
     return fail(FUS_ERR_STATE, "operator data was not created for two-field models (option fields=2)");
+  if (blk_count < 0)
+    blk_count = op->L.nblocks - blk_begin;
+  const int b0 = blk_begin, nb = blk_count;
   if (op->tdim == 2)  // quadrilaterals: streamed geometry only
     return op->deterministic
-               ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_STREAM, 2>(op, geo, coef, x, bvec, S)
-               : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_STREAM, 2>(op, geo, coef, x, bvec, S);
+               ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_STREAM, 2>(op, geo, coef, x, bvec, S, b0, nb)
+               : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_STREAM, 2>(op, geo, coef, x, bvec, S, b0, nb);
   // geometry operand: per-cell factors (affine meshes) or the streamed per-point arrays
   if (op->affine)
   {
     const T* gc = static_cast<const T*>(op->d_Gc);
     return op->deterministic
-               ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_AFFINE>(op, gc, coef, x, bvec, S)
-               : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_AFFINE>(op, gc, coef, x, bvec, S);
+               ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_AFFINE>(op, gc, coef, x, bvec, S, b0, nb)
+               : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_AFFINE>(op, gc, coef, x, bvec, S, b0, nb);
   }
   return op->deterministic
-             ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_STREAM>(op, geo, coef, x, bvec, S)
-             : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_STREAM>(op, geo, coef, x, bvec, S);
+             ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_STREAM>(op, geo, coef, x, bvec, S, b0, nb)
+             : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_STREAM>(op, geo, coef, x, bvec, S, b0, nb);
 }
 
 template <typename T>
@@ -381,9 +397,10 @@ static int halo_exchange_rccl(fus_op* op)
   NCCLCHK(g_rccl.GroupStart());
   for (auto& nb : op->neigh)
   {
-    NCCLCHK(g_rccl.Send(static_cast<char*>(op->d_sendbuf) + nb.off * op->ts, nb.count, dt, nb.rank,
+    const int peer = c->loopback ? 0 : nb.rank;
+    NCCLCHK(g_rccl.Send(static_cast<char*>(op->d_sendbuf) + nb.off * op->ts, nb.count, dt, peer,
                         c->comm, c->comm_stream));
-    NCCLCHK(g_rccl.Recv(static_cast<char*>(op->d_recvbuf) + nb.off * op->ts, nb.count, dt, nb.rank,
+    NCCLCHK(g_rccl.Recv(static_cast<char*>(op->d_recvbuf) + nb.off * op->ts, nb.count, dt, peer,
                         c->comm, c->comm_stream));
   }
   NCCLCHK(g_rccl.GroupEnd());
@@ -1021,24 +1038,34 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
   S.x2 = static_cast<const T*>(i == 0 ? m->v0 : m->vn);   // lossy: second operator input v_n
   const T* G = static_cast<const T*>(op->d_G);
   const T* coef = static_cast<const T*>(m->coef);
+  const int kind = stage_kind(m, i);
+  auto launch = [&](int b0, int nb) -> int
   {
-    ProfScope ps(m->ctx, "stiffness");
-    const int kind = stage_kind(m, i);
     if (m->kind == FUS_LOSSY || m->kind == FUS_WESTERVELT)
     {
       if (kind == 0)
-        FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 0, 2>(op, G, coef, ustage, b, S)));
-      else if (kind == 3)
-        FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 3, 2>(op, G, coef, ustage, b, S)));
-      else
-        FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 1, 2>(op, G, coef, ustage, b, S)));
+        return launch_block_op<T, P, OP_STIFFNESS, 0, 2>(op, G, coef, ustage, b, S, b0, nb);
+      if (kind == 3)
+        return launch_block_op<T, P, OP_STIFFNESS, 3, 2>(op, G, coef, ustage, b, S, b0, nb);
+      return launch_block_op<T, P, OP_STIFFNESS, 1, 2>(op, G, coef, ustage, b, S, b0, nb);
     }
-    else if (kind == 0)
-      FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 0>(op, G, coef, ustage, b, S)));
-    else if (kind == 3)
-      FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 3>(op, G, coef, ustage, b, S)));
-    else
-      FUSCHK((launch_block_op<T, P, OP_STIFFNESS, 1>(op, G, coef, ustage, b, S)));
+    if (kind == 0)
+      return launch_block_op<T, P, OP_STIFFNESS, 0>(op, G, coef, ustage, b, S, b0, nb);
+    if (kind == 3)
+      return launch_block_op<T, P, OP_STIFFNESS, 3>(op, G, coef, ustage, b, S, b0, nb);
+    return launch_block_op<T, P, OP_STIFFNESS, 1>(op, G, coef, ustage, b, S, b0, nb);
+  };
+  // Multi-rank, option "overlap_blocks": the blocks that touch interface dofs (first in the layout)
+  // run ahead, their partials are reduced, packed and handed to the exchange, and the remaining
+  // blocks (the bulk of the stage) run while the planes are in flight.  Off by default: the exchange
+  // already overlaps k_shared_stage, and on one GPU with the exchange looped back the extra small
+  // launch costs more (2.47 vs 2.41 ms per step at 64^3 p=4) than it hides.  A block's epilogue only writes that block's interior dofs,
+  // which no other block and none of the small kernels below reads.
+  const int nb_if = op->L.nblocks_if;
+  const bool split = m->ctx->overlap_blocks && !op->neigh.empty() && nb_if > 0 && nb_if < op->L.nblocks;
+  {
+    ProfScope ps(m->ctx, split ? "stiffness_if" : "stiffness");
+    FUSCHK(launch(0, split ? nb_if : -1));
   }
   // boundary terms of the shared boundary dofs become one more partial each
   hipStream_t st = m->ctx->stream;
@@ -1063,7 +1090,13 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
                        b + op->L.n_int_pad);
   }
   HIPCHK(hipGetLastError());
-  return halo_pack<T>(op, b);
+  FUSCHK(halo_pack<T>(op, b));
+  if (split)
+  {
+    ProfScope ps(m->ctx, "stiffness");
+    FUSCHK(launch(nb_if, op->L.nblocks - nb_if));
+  }
+  return FUS_OK;
 }
 
 // Stage i, second half, shared dofs only.  Rank-local shared dofs: fixed-order sum of the block
@@ -1471,6 +1504,10 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
       return fail(FUS_ERR_ARG, "geometry must be 0 (auto) or 1 (stream)");
     c->geometry = (int)value;
   }
+  else if (!strcmp(key, "halo_loopback"))
+    c->loopback = value != 0;
+  else if (!strcmp(key, "overlap_blocks"))
+    c->overlap_blocks = value != 0;
   else if (!strcmp(key, "fields"))
   {
     if (value != 1 && value != 2)
@@ -1503,7 +1540,10 @@ int fus_comm_init(fus_ctx* c, int rank, int nranks, const void* id128)
   ncclUniqueId id;
   memcpy(&id, id128, 128);
   HIPCHK(hipSetDevice(c->device));
-  NCCLCHK(g_rccl.CommInitRank(&c->comm, nranks, id, rank));
+  if (c->loopback)
+    NCCLCHK(g_rccl.CommInitRank(&c->comm, 1, id, 0));
+  else
+    NCCLCHK(g_rccl.CommInitRank(&c->comm, nranks, id, rank));
   return FUS_OK;
 }
 
@@ -2051,7 +2091,7 @@ int fus_profile_enable(fus_ctx* c, int on)
     for (auto& ev : kv.second.ev)
       (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
   c->profs.clear();
-  c->prof = on != 0;
+  c->prof = on < 0 ? 0 : (on > 2 ? 1 : on);
   return FUS_OK;
 }
 

@@ -41,6 +41,7 @@ struct BlockArgs
   const int16_t* rounds;
   const uint16_t* ldm;
   int32_t nblocks;
+  int32_t blk_begin; // first block of this launch (grid = a contiguous range of blocks)
   int32_t lds_nloc;  // LDS array length (>= max nloc, even)
   int32_t lds_nelem; // LDS per-element table length (>= max elements per block, multiple of 8)
   int32_t waves;
@@ -441,7 +442,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   uint16_t* ldm_l = reinterpret_cast<uint16_t*>(w_l + (GEOM == GEOM_AFFINE ? 8 : 0));  // 16-B aligned
   int16_t* rt_l = reinterpret_cast<int16_t*>(ldm_l + (size_t)A.lds_nelem * Nd);
 
-  const int blk = blockIdx.x;
+  const int blk = blockIdx.x + A.blk_begin;
   const int tid = threadIdx.x, nthr = blockDim.x;
   const ShapeDev sh = A.shapes[A.blk_shape[blk]];
   const int elem_off = A.blk_elem_off[blk];

@@ -83,6 +83,26 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
   for (auto& lf : leaves)
     std::sort(order.begin() + lf.first, order.begin() + lf.second);
 
+  // blocks touching a dof other ranks hold as well go first: the operator launches them ahead of
+  // the rest so that the interface exchange overlaps the remaining blocks (fusmi.hip stage_begin)
+  L.nblocks_if = 0;
+  if (force_shared)
+  {
+    auto touches = [&](const std::pair<int64_t, int64_t>& lf)
+    {
+      for (int64_t k = lf.first; k < lf.second; ++k)
+      {
+        const int32_t* d = dm + (int64_t)order[k] * Nd;
+        for (int i = 0; i < Nd; ++i)
+          if (d[i] >= 0 && d[i] < ndofs && force_shared[d[i]])
+            return true;
+      }
+      return false;
+    };
+    auto mid = std::stable_partition(leaves.begin(), leaves.end(), touches);
+    L.nblocks_if = (int32_t)(mid - leaves.begin());
+  }
+
   // ---- 2. how many blocks touch each dof ----
   std::vector<int32_t> last_blk(ndofs, -1);
   std::vector<uint8_t> nblk(ndofs, 0);

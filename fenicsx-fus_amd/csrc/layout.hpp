@@ -27,6 +27,7 @@ struct Layout
 
   // --- cells ---
   int32_t nblocks = 0;
+  int32_t nblocks_if = 0;             // blocks [0, nblocks_if) touch interface dofs (held by other ranks too)
   std::vector<int32_t> cell_perm;     // [ncells] internal element -> caller cell
   std::vector<int32_t> blk_elem_off;  // [nblocks+1] first internal element of block
 

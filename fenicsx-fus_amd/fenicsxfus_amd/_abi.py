@@ -126,7 +126,7 @@ class Context:
             c.rank, c.nranks = i, len(ctxs)
 
     def profile_enable(self, on: bool = True):
-        check(lib().fus_profile_enable(self.h, C.c_int(int(on))))
+        check(lib().fus_profile_enable(self.h, C.c_int(int(on))))   # 1: all kernels, 2: block operator only
 
     def profile_get(self, name: str):
         ms, n = C.c_double(), C.c_int64()

@@ -49,12 +49,17 @@ int fus_init(int device, fus_ctx** ctx);
 int fus_finalize(fus_ctx* ctx);
 int fus_synchronize(fus_ctx* ctx);
 /* Tunables, set before fus_op_create: "block_elems" (elements per LDS block) and "waves"
- * (waves per workgroup; 1, 2, 4 or 8): default 0 = auto (32 / 4 when G is streamed, 16 / 4 on the
- * affine path), "geometry" (0 auto | 1 always stream the
- * per-point factors), "fields" (1 | 2: operator inputs the block kernel
+ * (waves per workgroup; 1, 2, 4 or 8): default 0 = auto (hexahedra with G streamed: 128 / 64 / 32
+ * elements at P = 2 / 3 / >= 4, half of that on the affine path; 4 waves), "geometry" (0 auto |
+ * 1 always stream the per-point factors), "fields" (1 | 2: operator inputs the block kernel
  * stages per pass; 2 is required by FUS_LOSSY), "deterministic" (1: elements accumulate in
  * conflict-free rounds, results bitwise reproducible; 0 (default): LDS floating-point atomics, the
- * order of the <= 8 adds per DOF inside a block is free).  Unknown keys -> FUS_ERR_ARG. */
+ * order of the <= 8 adds per DOF inside a block is free).
+ * Multi-rank, set before fus_comm_init / fus_model_create: "overlap_blocks" (1: the blocks touching
+ * interface DOFs are launched first and the exchange overlaps the remaining blocks; default 0: it
+ * overlaps the shared-DOF kernel only), "halo_loopback" (1: timing rehearsal on one GPU -- a 1-rank
+ * communicator, every send/receive goes to the own rank; results are not the physical ones).
+ * Unknown keys -> FUS_ERR_ARG. */
 int fus_set_option(fus_ctx* ctx, const char* key, int64_t value);
 
 /* Multi-GPU: one process per GPU.  fus_comm_unique_id fills a 128-byte RCCL id on rank 0; the
@@ -186,7 +191,10 @@ int fus_group_rk4_steps(fus_model** models, int n, double t0, double dt, int64_t
 /* ---- measurement -----------------------------------------------------------------------------
  * HIP-event timing of the library's own kernels on the stream they run on.  Names:
  * "stiffness" (block operator kernel), "shared" (shared-DOF reduction), "stage" (fused RK stage
- * update), "boundary", "halo".  total_ms/count accumulate since the last enable. */
+ * update), "boundary", "halo".  total_ms/count accumulate since the last enable.
+ * on = 1: every kernel; on = 2: only the block operator kernel ("stiffness", and "stiffness_if" when
+ * the interface blocks are launched separately) -- an event record drains the queue between two
+ * kernels, so timed runs use 2 (bench.py) and take the full breakdown in a separate pass. */
 int fus_profile_enable(fus_ctx* ctx, int on);
 int fus_profile_get(fus_ctx* ctx, const char* name, double* total_ms, int64_t* count);
 

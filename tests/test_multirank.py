@@ -171,6 +171,48 @@ def test_slabs_in_process_gpu(orc, size):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_slabs_overlap_blocks_option_gpu(orc, overlap):
+    """Option "overlap_blocks": interface blocks launched first, the remaining blocks after the pack.
+    Elongated box so that the 1 x 2 x 2 blocks next to the cut are a strict subset of each rank's
+    blocks; both settings must give the single-rank oracle's state."""
+    n, hi, size, nsteps = (12, 2, 2), [0.048, 0.008, 0.008], 2, 5
+    pr = Problem(orc, n, P, hi=hi)
+    nc = pr.mesh.num_cells
+    c, rho = np.full(nc, 1500.0), np.full(nc, 1000.0)
+    m, src, absb, coeff = pr.linear_model_vectors(c, rho, fa.tag_box_boundary(pr.mesh))
+    dt = 0.5 * (hi[0] / n[0]) / (1500.0 * P**2)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, F0, P0, S0, 0.0, nsteps * dt * (1 + 1e-12), dt, u, v)
+    ctxs = [fa.Context(0, block_elems=4) for _ in range(size)]
+    for cx in ctxs:
+        cx.set_option("overlap_blocks", overlap)
+    fa.Context.init_local_group(ctxs)
+    models, offs = [], []
+    for r in range(size):
+        mesh = fa.BoxMesh([0, 0, 0], hi, n, rank=r, size=size)
+        V = fa.FunctionSpace(mesh, P)
+        k = mesh.num_cells
+        models.append(fa.LinearSpectralExplicit(mesh, fa.tag_box_boundary(mesh), P, np.full(k, 1500.0),
+                                                np.full(k, 1000.0), F0, P0, S0, 4, dt, V=V, ctx=ctxs[r]))
+        assert models[-1].data.info()["nblocks"] == 6
+        offs.append(V.global_offset)
+    fa.group_finish_setup(models)
+    for mdl in models:
+        mdl.init()
+    fa.group_rk4_steps(models, 0.0, dt, nsteps)
+    for r, mdl in enumerate(models):
+        k = mdl.data.ndofs
+        assert np.abs(u).max() > 0
+        assert np.abs(mdl.u_sol().x.array - u[offs[r]:offs[r] + k]).max() < 1e-10 * np.abs(u).max()
+        assert np.abs(mdl.v_n.x.array - v[offs[r]:offs[r] + k]).max() < 1e-10 * np.abs(v).max()
+    for mdl in models:
+        mdl.close()
+    for cx in ctxs:
+        cx.close()
+
+
+@pytest.mark.gpu
 def test_westervelt_slabs_in_process_gpu(orc):
     # the nonlinear model across 2 slabs: m0 and the M(nlin1) diagonal are summed over the sharers
     pr = Problem(orc, N_GLOBAL, P, hi=HI, perturb=0.1)

@@ -1080,17 +1080,18 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
                        static_cast<const T*>(i == 0 ? m->v0 : m->vn),
                        static_cast<T*>(op->d_partial) + op->L.npairs);
   }
-  // interface dofs (held by other ranks too): reduce this rank's partials into b and pack them
-  const int64_t s0 = op->L.n_if_start_pad, s1 = op->L.n_shared;
-  if (s1 > s0)
+  // interface dofs (held by other ranks too): this rank's partials are summed into b and into the
+  // send buffer by one kernel; the event hands the buffer to the exchange
+  if (!op->neigh.empty())
   {
-    ProfScope ps(m->ctx, "shared");
-    hipLaunchKernelGGL((k_shared_reduce<T, int32_t>), dim3(nblk(s1 - s0)), dim3(256), 0, st, s0, s1,
-                       m->d_sh_ptr32, m->d_sh_pairs32, static_cast<const T*>(op->d_partial),
-                       b + op->L.n_int_pad);
+    ProfScope ps(m->ctx, "halo");
+    hipLaunchKernelGGL((k_if_reduce_pack<T>), dim3(nblk(op->n_halo)), dim3(256), 0, st, op->n_halo,
+                       op->d_pack_idx, op->L.n_int_pad, m->d_sh_ptr32, m->d_sh_pairs32,
+                       static_cast<const T*>(op->d_partial), b, static_cast<T*>(op->d_sendbuf));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(m->ctx->ev_packed, st));
   }
   HIPCHK(hipGetLastError());
-  FUSCHK(halo_pack<T>(op, b));
   if (split)
   {
     ProfScope ps(m->ctx, "stiffness");
@@ -1101,7 +1102,7 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
 
 // Stage i, second half, shared dofs only.  Rank-local shared dofs: fixed-order sum of the block
 // partials fused with the stage update (k_shared_stage).  Interface dofs: ordered sum of the
-// sharers' totals (halo_unpack) followed by k_stage on that index range.
+// sharers' totals fused with the same update (k_if_unpack_stage).
 template <typename T>
 static int stage_end(fus_model* m, int i, double t, double dt)
 {
@@ -1141,34 +1142,33 @@ static int stage_end(fus_model* m, int i, double t, double dt)
                          v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p);
     }
   }
-  if (op->L.n_shared > op->L.n_if_start_pad)
+  if (!op->neigh.empty())
   {
     // (the rank-local shared dofs above ran while the interface planes were in flight)
-    FUSCHK(halo_unpack<T>(op, b));
+    // ordered sum of the sharers' totals fused with the stage update of the interface dofs
+    if (!c->local_group)
+      HIPCHK(hipStreamWaitEvent(st, c->ev_recv, 0));
     ProfScope ps(c, "stage");
-    // interface range of the internal vectors; start and length are multiples of 16
-    const int64_t o2 = off + op->L.n_if_start_pad;
-    const int64_t n2 = op->L.n_internal - o2;
-    const unsigned grid = (unsigned)std::min<int64_t>(nblk(n2 / (16 / sizeof(T))), 256 * 16);
+    const dim3 grid(nblk(op->n_uidx)), blk(256);
+    const T* recv = static_cast<const T*>(op->d_recvbuf);
+    const T* m0f = m->mn1 ? static_cast<const T*>(m->m) : nullptr;
+    const T* mn1f = m->mn1 ? static_cast<const T*>(m->mn1) : nullptr;
     switch (stage_kind(m, i))
     {
     case 0:
-      hipLaunchKernelGGL((k_stage<T, 0>), dim3(grid), dim3(256), 0, st, n2, b + o2, minv + o2,
-                         vn + o2, un + o2, u0 + o2, v0 + o2, u_ + o2, v_ + o2, adt, bdt,
-                         m->mn1 ? static_cast<const T*>(m->m) + o2 : nullptr,
-                         m->mn1 ? static_cast<const T*>(m->mn1) + o2 : nullptr);
+      hipLaunchKernelGGL((k_if_unpack_stage<T, 0>), grid, blk, 0, st, op->n_uidx, op->d_uidx,
+                         op->d_uptr, op->d_usrc, recv, b, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0f,
+                         mn1f);
       break;
     case 3:
-      hipLaunchKernelGGL((k_stage<T, 3>), dim3(grid), dim3(256), 0, st, n2, b + o2, minv + o2,
-                         vn + o2, un + o2, u0 + o2, v0 + o2, u_ + o2, v_ + o2, adt, bdt,
-                         m->mn1 ? static_cast<const T*>(m->m) + o2 : nullptr,
-                         m->mn1 ? static_cast<const T*>(m->mn1) + o2 : nullptr);
+      hipLaunchKernelGGL((k_if_unpack_stage<T, 3>), grid, blk, 0, st, op->n_uidx, op->d_uidx,
+                         op->d_uptr, op->d_usrc, recv, b, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0f,
+                         mn1f);
       break;
     default:
-      hipLaunchKernelGGL((k_stage<T, 1>), dim3(grid), dim3(256), 0, st, n2, b + o2, minv + o2,
-                         vn + o2, un + o2, u0 + o2, v0 + o2, u_ + o2, v_ + o2, adt, bdt,
-                         m->mn1 ? static_cast<const T*>(m->m) + o2 : nullptr,
-                         m->mn1 ? static_cast<const T*>(m->mn1) + o2 : nullptr);
+      hipLaunchKernelGGL((k_if_unpack_stage<T, 1>), grid, blk, 0, st, op->n_uidx, op->d_uidx,
+                         op->d_uptr, op->d_usrc, recv, b, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0f,
+                         mn1f);
     }
   }
   HIPCHK(hipGetLastError());

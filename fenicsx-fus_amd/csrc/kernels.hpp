@@ -6,8 +6,8 @@
 //                        cpp/fenicsx-sf/common/spectral_op.hpp:173-243, 69-86)
 //   k_shared_reduce<T>   fixed-order sum of per-block partials of shared DOFs
 //                        (replaces the `+=` scatter of spectral_op.hpp:240-241 across blocks)
-//   k_stage<T,STAGE>     fused RK4 stage update (reference: 9 separate vector passes per stage,
-//                        Linear.hpp:274-294 + :212-221)
+//   k_shared_stage<T,S>  / epilogue of k_block_op: fused RK4 stage update (reference: 9 separate
+//                        vector passes per stage, Linear.hpp:274-294 + :212-221)
 //
 // Thread mapping of k_block_op (wave = 64 lanes): lane p = (b, c) of the N x N plane
 // (tensor indices 1 and 2), registers run along tensor index 0; EPW = 64 / N^2 elements per wave
@@ -741,24 +741,23 @@ __global__ void k_shared_reduce(int64_t s0, int64_t s1, const I* __restrict__ sh
   bsh[s] = acc;
 }
 
-// Shared dofs of one rank: fixed-order sum of the partials fused with the RK4 stage update of
-// k_stage (same formulas); vectors are passed offset to the shared range.
+// Fused RK4 stage update of ONE dof s whose right-hand side sum `acc` (= b) is complete.
+// kv = b * minv  (Linear.hpp:212-221), ku = vn (f0, :171-174).
+//   STAGE 0 : vn == v0, un == u0, u_ == u0, v_ == v0 (aliases are not read twice)
+//             u_ = u0 + bdt*v0 ; v_ = v0 + bdt*kv ; un' = u0 + adt*v0 ; vn' = v0 + adt*kv
+//   STAGE 1,2: u_ += bdt*vn ; v_ += bdt*kv ; un' = u0 + adt*vn ; vn' = v0 + adt*kv
+//   STAGE 3 : u0 = u_ + bdt*vn ; v0 = v_ + bdt*kv        (next step's state, no copies)
+// adt = dt*a_{i+1}, bdt = dt*b_i (Linear.hpp:282-294).
+//
+// Model vectors are read / written once per stage: non-temporal, so that the partial slab (written
+// just before by k_block_op) stays cache resident.
 template <typename T, int STAGE>
-__global__ void __launch_bounds__(256)
-k_shared_stage(int64_t n, const int32_t* __restrict__ sh_ptr, const int32_t* __restrict__ sh_pairs,
-               const T* __restrict__ partial, const T* __restrict__ minv, T* __restrict__ vn,
-               T* __restrict__ un, T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ u_,
-               T* __restrict__ v_, T adt, T bdt, const T* __restrict__ m0,
-               const T* __restrict__ mn1)
+__device__ __forceinline__ void stage_update_dof(int64_t s, T acc, const T* __restrict__ minv,
+                                                 T* __restrict__ vn, T* __restrict__ un,
+                                                 T* __restrict__ u0, T* __restrict__ v0,
+                                                 T* __restrict__ u_, T* __restrict__ v_, T adt, T bdt,
+                                                 const T* __restrict__ m0, const T* __restrict__ mn1)
 {
-  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= n)
-    return;
-  T acc = T(0);
-  for (int32_t k = sh_ptr[s]; k < sh_ptr[s + 1]; ++k)
-    acc += partial[sh_pairs[k]];
-  // model vectors are read / written once per stage: non-temporal, so that the partial slab (written
-  // just before by k_block_op) stays cache resident
 #define FUS_LD(p) __builtin_nontemporal_load(&(p)[s])
 #define FUS_ST(p, val) __builtin_nontemporal_store((val), &(p)[s])
   T kv;
@@ -794,6 +793,73 @@ k_shared_stage(int64_t n, const int32_t* __restrict__ sh_ptr, const int32_t* __r
 #undef FUS_ST
 }
 
+// Shared dofs of one rank: fixed-order sum of the partials fused with the RK4 stage update of
+// stage_update_dof; vectors are passed offset to the shared range.
+template <typename T, int STAGE>
+__global__ void __launch_bounds__(256)
+k_shared_stage(int64_t n, const int32_t* __restrict__ sh_ptr, const int32_t* __restrict__ sh_pairs,
+               const T* __restrict__ partial, const T* __restrict__ minv, T* __restrict__ vn,
+               T* __restrict__ un, T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ u_,
+               T* __restrict__ v_, T adt, T bdt, const T* __restrict__ m0,
+               const T* __restrict__ mn1)
+{
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n)
+    return;
+  T acc = T(0);
+  for (int32_t k = sh_ptr[s]; k < sh_ptr[s + 1]; ++k)
+    acc += partial[sh_pairs[k]];
+  stage_update_dof<T, STAGE>(s, acc, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0, mn1);
+}
+
+// Interface dofs (held by other ranks too), first half of the exchange: this rank's total of each
+// packed dof = fixed-order sum of its block partials, written to the send buffer and to b.
+// pack_idx[k] is the dof's index in the internal vectors, sh0 the index of shared slot 0; a dof
+// listed for two neighbours is summed twice to the same bits.
+template <typename T>
+__global__ void k_if_reduce_pack(int64_t n, const int32_t* __restrict__ pack_idx, int64_t sh0,
+                                 const int32_t* __restrict__ sh_ptr,
+                                 const int32_t* __restrict__ sh_pairs,
+                                 const T* __restrict__ partial, T* __restrict__ b,
+                                 T* __restrict__ sendbuf)
+{
+  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n)
+    return;
+  const int64_t u = pack_idx[k], s = u - sh0;
+  T acc = T(0);
+  for (int32_t q = sh_ptr[s]; q < sh_ptr[s + 1]; ++q)
+    acc += partial[sh_pairs[q]];
+  sendbuf[k] = acc;
+  b[u] = acc;
+}
+
+// Second half: every sharer adds the ranks' totals of an interface dof in ascending rank order
+// (identical bits everywhere, see k_unpack_ordered) and finishes the RK stage for it.  Vectors are
+// passed whole (internal numbering).
+template <typename T, int STAGE>
+__global__ void __launch_bounds__(256)
+k_if_unpack_stage(int64_t nu, const int32_t* __restrict__ uidx, const int32_t* __restrict__ uptr,
+                  const int32_t* __restrict__ usrc, const T* __restrict__ recvbuf,
+                  const T* __restrict__ b, const T* __restrict__ minv, T* __restrict__ vn,
+                  T* __restrict__ un, T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ u_,
+                  T* __restrict__ v_, T adt, T bdt, const T* __restrict__ m0,
+                  const T* __restrict__ mn1)
+{
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nu)
+    return;
+  const int64_t u = uidx[j];
+  const T own = b[u];
+  T acc = T(0);
+  for (int32_t k = uptr[j]; k < uptr[j + 1]; ++k)
+  {
+    const int32_t sidx = usrc[k];
+    acc += (sidx < 0) ? own : recvbuf[sidx];
+  }
+  stage_update_dof<T, STAGE>(u, acc, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0, mn1);
+}
+
 // Boundary term of shared boundary dofs, written as one more partial (summed last):
 // slot[k] = g(t) src[k] - abs[k] * v_stage[idx[k]]     (Linear.hpp:205; forms.py:38-39)
 template <typename T>
@@ -824,63 +890,6 @@ __global__ void k_boundary(int64_t nb, const int32_t* __restrict__ idx, const T*
     return;
   const int32_t i = idx[k];
   b[i] += gval * srcw[k] - absw[k] * vn[i];
-}
-
-// Fused RK4 stage update.  kv = b * minv  (Linear.hpp:212-221), ku = vn (f0, :171-174).
-//   STAGE 0 : vn == v0, un == u0, u_ == u0, v_ == v0 (aliases are not read twice)
-//             u_ = u0 + bdt*v0 ; v_ = v0 + bdt*kv ; un' = u0 + adt*v0 ; vn' = v0 + adt*kv
-//   STAGE 1,2: u_ += bdt*vn ; v_ += bdt*kv ; un' = u0 + adt*vn ; vn' = v0 + adt*kv
-//   STAGE 3 : u0 = u_ + bdt*vn ; v0 = v_ + bdt*kv        (next step's state, no copies)
-// adt = dt*a_{i+1}, bdt = dt*b_i (Linear.hpp:282-294).
-template <typename T, int STAGE>
-__global__ void __launch_bounds__(256)
-k_stage(int64_t n, const T* __restrict__ b, const T* __restrict__ minv, T* __restrict__ vn,
-        T* __restrict__ un, T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ u_,
-        T* __restrict__ v_, T adt, T bdt, const T* __restrict__ m0 = nullptr,
-        const T* __restrict__ mn1 = nullptr)
-{
-  typedef T V __attribute__((ext_vector_type(16 / sizeof(T))));
-  constexpr int VW = 16 / sizeof(T);
-  const int64_t nv = n / VW;  // n is a multiple of 16
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv;
-       i += (int64_t)gridDim.x * blockDim.x)
-  {
-    V kv;
-    if (mn1)  // Westervelt (see StageArgs); padding slots have m0 = mn1 = 0 and b = 0
-    {
-      const V us = reinterpret_cast<const V*>(STAGE == 0 ? u0 : un)[i];
-      const V vs = reinterpret_cast<const V*>(STAGE == 0 ? v0 : vn)[i];
-      const V m1 = reinterpret_cast<const V*>(mn1)[i];
-      V den = reinterpret_cast<const V*>(m0)[i] + m1 * us;
-      for (int k = 0; k < VW; ++k)
-        den[k] = (den[k] != T(0)) ? den[k] : T(1);
-      kv = (reinterpret_cast<const V*>(b)[i] - m1 * vs * vs) / den;
-    }
-    else
-      kv = reinterpret_cast<const V*>(b)[i] * reinterpret_cast<const V*>(minv)[i];
-    if (STAGE == 0)
-    {
-      const V u = reinterpret_cast<const V*>(u0)[i], v = reinterpret_cast<const V*>(v0)[i];
-      reinterpret_cast<V*>(u_)[i] = v * bdt + u;
-      reinterpret_cast<V*>(v_)[i] = kv * bdt + v;
-      reinterpret_cast<V*>(un)[i] = v * adt + u;
-      reinterpret_cast<V*>(vn)[i] = kv * adt + v;
-    }
-    else if (STAGE == 3)
-    {
-      const V w = reinterpret_cast<const V*>(vn)[i];
-      reinterpret_cast<V*>(u0)[i] = w * bdt + reinterpret_cast<const V*>(u_)[i];
-      reinterpret_cast<V*>(v0)[i] = kv * bdt + reinterpret_cast<const V*>(v_)[i];
-    }
-    else
-    {
-      const V w = reinterpret_cast<const V*>(vn)[i];
-      reinterpret_cast<V*>(u_)[i] = w * bdt + reinterpret_cast<const V*>(u_)[i];
-      reinterpret_cast<V*>(v_)[i] = kv * bdt + reinterpret_cast<const V*>(v_)[i];
-      reinterpret_cast<V*>(un)[i] = w * adt + reinterpret_cast<const V*>(u0)[i];
-      reinterpret_cast<V*>(vn)[i] = kv * adt + reinterpret_cast<const V*>(v0)[i];
-    }
-  }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -154,6 +154,11 @@ struct fus_ctx
   // and synchronisation cost (the received planes are its own: results are NOT the physical ones)
   bool loopback = false;
   bool overlap_blocks = false;  // launch interface blocks first, overlap the exchange with the rest
+  // Lossy / Westervelt boundary forms: 0 = the C++ benchmarks (BM7-SC1/forms.py:37-42: absorbing and
+  // delta-mass terms on every boundary facet, source doubled, Lossy.hpp:216-220); 1 = the Python
+  // package (python/src/fenicsxfus/_lossy.py:107-128, :186-189: those terms on tag 2 only, source
+  // not doubled)
+  int forms = 0;
 };
 
 struct Neigh
@@ -221,6 +226,7 @@ struct fus_model
   bool initialised = false;
   bool setup_done = false;
   int rk_order = 4;  // explicit Runge-Kutta scheme, tables of python/src/fenicsxfus/_linear.py:286-311
+  int forms = 0;     // fus_ctx::forms at creation
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -825,8 +831,8 @@ static int model_setup(fus_model* m, const void* c0_, const void* rho0_, const v
       return fail(FUS_ERR_ARG, "facet (cell, local facet) out of range");
     if (ft[f] == 1)
       c1.push_back(fc[f]), l1.push_back(fl[f]);
-    if (lossy || ft[f] == 2)
-      c2.push_back(fc[f]), l2.push_back(fl[f]);   // lossy: plain ds = every listed facet
+    if ((lossy && m->forms == 0) || ft[f] == 2)
+      c2.push_back(fc[f]), l2.push_back(fl[f]);   // lossy, C++ forms: plain ds = every listed facet
   }
   facet_diag_host<T>(op, (int64_t)c1.size(), c1.data(), l1.data(), cs.data(), src.data());
   facet_diag_host<T>(op, (int64_t)c2.size(), c2.data(), l2.data(), ca.data(), absb.data());
@@ -984,9 +990,10 @@ static StageScalars stage_scalars(const fus_model* m, int i, double t_, double d
   if (m->kind == FUS_LOSSY || m->kind == FUS_WESTERVELT)
   {
     // heterogeneous-domain scaling, live in Lossy.hpp:216-220 (factor 2) and its derivative dg
-    sc.gval = (double)(window * (T)2.0 * p0 * w0 / s0 * (T)std::cos((double)(w0 * tn)));
-    sc.dgval = (double)(dwindow * (T)2.0 * p0 * w0 / s0 * (T)std::cos((double)(w0 * tn))
-                        - window * (T)2.0 * p0 * w0 * w0 / s0 * (T)std::sin((double)(w0 * tn)));
+    const T two = m->forms == 0 ? (T)2.0 : (T)1.0;  // "heterogenous domain" doubling, Lossy.hpp:216-220
+    sc.gval = (double)(window * two * p0 * w0 / s0 * (T)std::cos((double)(w0 * tn)));
+    sc.dgval = (double)(dwindow * two * p0 * w0 / s0 * (T)std::cos((double)(w0 * tn))
+                        - window * two * p0 * w0 * w0 / s0 * (T)std::sin((double)(w0 * tn)));
   }
   else
   {
@@ -1508,6 +1515,12 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
     c->loopback = value != 0;
   else if (!strcmp(key, "overlap_blocks"))
     c->overlap_blocks = value != 0;
+  else if (!strcmp(key, "forms"))
+  {
+    if (value != 0 && value != 1)
+      return fail(FUS_ERR_ARG, "forms must be 0 (C++ benchmark forms) or 1 (Python package forms)");
+    c->forms = (int)value;
+  }
   else if (!strcmp(key, "fields"))
   {
     if (value != 1 && value != 2)
@@ -1854,6 +1867,7 @@ int fus_model_create(fus_ctx* c, int kind, fus_op* op, const void* c0, const voi
   HIPCHK(hipSetDevice(c->device));
   std::unique_ptr<fus_model> m(new fus_model());
   m->ctx = c, m->op = op, m->kind = kind, m->freq = freq, m->amp = amp, m->speed = speed;
+  m->forms = c->forms;
   int r = d_model_setup(m.get(), c0, rho0, delta0, beta0, nfacets, facet_cells, facet_local, facet_tags);
   if (r == FUS_OK && !c->local_group)
   {

@@ -22,9 +22,12 @@ class _SpectralExplicit:
 
     _kind = _abi.FUS_LINEAR
 
-    def _create(self, mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt, V, ctx, beta0=None):
+    def _create(self, mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt, V, ctx, beta0=None,
+                forms="cpp"):
         if rk_order not in (1, 2, 3, 4):
             raise _abi.FusError("rk_order must be 1, 2, 3 or 4 (_linear.py:286-311)")
+        if forms not in ("cpp", "python"):
+            raise _abi.FusError("forms must be 'cpp' or 'python'")
         self.mesh, self.dt = mesh, dt
         self.freq, self.p0, self.s0 = float(freq0), float(p0), float(s0)
         self.V = V or FunctionSpace(mesh, k)
@@ -39,10 +42,14 @@ class _SpectralExplicit:
         lf = np.ascontiguousarray(meshtags.local_facets, dtype=np.int32)
         tags = np.ascontiguousarray(meshtags.values, dtype=np.int32)
         self.h = C.c_void_p()
-        check(lib().fus_model_create(self.ctx.h, C.c_int(self._kind), self.data.h, ptr(c0a), ptr(rhoa),
-                                     ptr(dla), ptr(bta), C.c_int64(len(cells)), ptr(cells), ptr(lf), ptr(tags),
-                                     C.c_double(self.freq), C.c_double(self.p0), C.c_double(self.s0),
-                                     C.byref(self.h)))
+        self.ctx.set_option("forms", 1 if forms == "python" else 0)
+        try:
+            check(lib().fus_model_create(self.ctx.h, C.c_int(self._kind), self.data.h, ptr(c0a), ptr(rhoa),
+                                         ptr(dla), ptr(bta), C.c_int64(len(cells)), ptr(cells), ptr(lf), ptr(tags),
+                                         C.c_double(self.freq), C.c_double(self.p0), C.c_double(self.s0),
+                                         C.byref(self.h)))
+        finally:
+            self.ctx.set_option("forms", 0)
         check(lib().fus_model_set_rk_order(self.h, C.c_int(rk_order)))
         self.u_n = Function(self.V, dt_)
         self.v_n = Function(self.V, dt_)
@@ -115,30 +122,37 @@ class LinearSpectralExplicit(_SpectralExplicit):
 
 class LossySpectralExplicit(_SpectralExplicit):
     """``LossySpectralExplicit(mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt)``
-    (python/src/fenicsxfus/_lossy.py:21-23; C++ ``LossySpectral3D``, Lossy.hpp:56-62).  Absorbing
-    term on every listed boundary facet, ``delta0`` = diffusivity of sound (DG0)."""
+    (python/src/fenicsxfus/_lossy.py:21-23; C++ ``LossySpectral3D``, Lossy.hpp:56-62).
+    ``delta0`` = diffusivity of sound (DG0).  The reference has two variants of the boundary forms:
+    ``forms="cpp"`` (default) is the C++ one -- absorbing and delta-mass terms on every listed
+    boundary facet (BM7-SC1/forms.py:37-42) and the source doubled (Lossy.hpp:216-220);
+    ``forms="python"`` is the Python package's -- those terms on tag 2 only, source not doubled
+    (_lossy.py:107-128, :186-189)."""
 
     _kind = _abi.FUS_LOSSY
 
     def __init__(self, mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order=4, dt=None, V=None,
-                 ctx: Context | None = None):
-        self._create(mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt, V, ctx)
+                 ctx: Context | None = None, forms="cpp"):
+        self._create(mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt, V, ctx, forms=forms)
 
 
 class WesterveltSpectralExplicit(_SpectralExplicit):
     """``WesterveltSpectralExplicit(mesh, meshtags, k, c0, rho0, delta0, beta0, freq0, p0, s0,
     rk_order, dt)`` (python/src/fenicsxfus/_westervelt.py:21-23; C++ ``WesterveltSpectral3D``,
-    Westervelt.hpp:58-67).  ``beta0`` = coefficient of nonlinearity (DG0)."""
+    Westervelt.hpp:58-67).  ``beta0`` = coefficient of nonlinearity (DG0); ``forms`` as in
+    :class:`LossySpectralExplicit` (_westervelt.py:107-142, :215)."""
 
     _kind = _abi.FUS_WESTERVELT
 
     def __init__(self, mesh, meshtags, k, c0, rho0, delta0, beta0, freq0, p0, s0, rk_order=4, dt=None, V=None,
-                 ctx: Context | None = None):
-        self._create(mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt, V, ctx, beta0=beta0)
+                 ctx: Context | None = None, forms="cpp"):
+        self._create(mesh, meshtags, k, c0, rho0, delta0, freq0, p0, s0, rk_order, dt, V, ctx, beta0=beta0,
+                     forms=forms)
 
 
 def compute_diffusivity_of_sound(w0: float, c0: float, alpha: float) -> float:
-    """delta = 2 alpha c0^3 / w0^2 (Lossy.hpp:376-381; python/src/fenicsxfus/utils.py)."""
+    """delta = 2 alpha c0^3 / w0^2 with alpha in Np/m (the C++ helper, Lossy.hpp:375-379).  The
+    Python package's helper of the same name takes dB/m: :func:`fenicsxfus_amd.utils.compute_diffusivity_of_sound`."""
     return 2 * alpha * c0**3 / w0**2
 
 

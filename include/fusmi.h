@@ -55,6 +55,10 @@ int fus_synchronize(fus_ctx* ctx);
  * stages per pass; 2 is required by FUS_LOSSY), "deterministic" (1: elements accumulate in
  * conflict-free rounds, results bitwise reproducible; 0 (default): LDS floating-point atomics, the
  * order of the <= 8 adds per DOF inside a block is free).
+ * "forms" (set before fus_model_create; FUS_LOSSY / FUS_WESTERVELT): 0 (default) the C++ benchmark
+ * forms -- absorbing and delta-mass terms on every listed boundary facet (BM7-SC1/forms.py:37-42),
+ * source doubled (Lossy.hpp:216-220); 1 the Python package's -- those terms on tag 2 only, source
+ * not doubled (python/src/fenicsxfus/_lossy.py:107-128, :186-189).
  * Multi-rank, set before fus_comm_init / fus_model_create: "overlap_blocks" (1: the blocks touching
  * interface DOFs are launched first and the exchange overlaps the remaining blocks; default 0: it
  * overlaps the shared-DOF kernel only), "halo_loopback" (1: timing rehearsal on one GPU -- a 1-rank

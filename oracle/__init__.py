@@ -183,32 +183,34 @@ def linear_rk4(tdim, N, tensor_dofmap, G, D, coeff, m, src, absb, freq, p0, s0, 
 
 
 def lossy_rk4(tdim, N, tensor_dofmap, G, D, lin_coeff, att_coeff, m, src, absb, src2, freq, p0, s0, t0, tf, dt,
-              u, v, dtype=np.float64, fast=False):
-    """Lossy.hpp rk4 restated; u, v updated in place; returns the number of steps taken."""
+              u, v, dtype=np.float64, fast=False, source_scale=2.0):
+    """Lossy.hpp rk4 restated; u, v updated in place; returns the number of steps taken.
+    source_scale 2: Lossy.hpp:216-220; 1: the Python package's unscaled source (_lossy.py:186-189)."""
     dm = _arr(tensor_dofmap, np.int32)
-    fn = getattr(lib(fast), "orc_lossy_rk4_" + _suf(dtype))
+    fn = getattr(lib(fast), "orc_lossy_rk4_s_" + _suf(dtype))
     fn.restype = C.c_int64
     assert u.flags.c_contiguous and v.flags.c_contiguous
     return fn(
         C.c_int(tdim), C.c_int64(dm.shape[0]), C.c_int64(len(u)), C.c_int(N), _p(dm), _p(_arr(G, dtype)),
         _p(_arr(D, dtype)), _p(_arr(lin_coeff, dtype)), _p(_arr(att_coeff, dtype)), _p(_arr(m, dtype)),
         _p(_arr(src, dtype)), _p(_arr(absb, dtype)), _p(_arr(src2, dtype)), C.c_double(freq), C.c_double(p0),
-        C.c_double(s0), C.c_double(t0), C.c_double(tf), C.c_double(dt), _p(u), _p(v)
+        C.c_double(s0), C.c_double(t0), C.c_double(tf), C.c_double(dt), _p(u), _p(v), C.c_double(source_scale)
     )
 
 
 def westervelt_rk4(tdim, N, tensor_dofmap, G, detJ, D, lin_coeff, att_coeff, nlin1, nlin2, m0, src, absb, src2,
-                   freq, p0, s0, t0, tf, dt, u, v, dtype=np.float64, fast=False):
+                   freq, p0, s0, t0, tf, dt, u, v, dtype=np.float64, fast=False, source_scale=2.0):
     """Westervelt.hpp rk4 restated; u, v updated in place; returns the number of steps taken."""
     dm = _arr(tensor_dofmap, np.int32)
-    fn = getattr(lib(fast), "orc_westervelt_rk4_" + _suf(dtype))
+    fn = getattr(lib(fast), "orc_westervelt_rk4_s_" + _suf(dtype))
     fn.restype = C.c_int64
     assert u.flags.c_contiguous and v.flags.c_contiguous
     a = lambda x: _p(_arr(x, dtype))  # noqa: E731
     return fn(
         C.c_int(tdim), C.c_int64(dm.shape[0]), C.c_int64(len(u)), C.c_int(N), _p(dm), a(G), a(detJ), a(D),
         a(lin_coeff), a(att_coeff), a(nlin1), a(nlin2), a(m0), a(src), a(absb), a(src2), C.c_double(freq),
-        C.c_double(p0), C.c_double(s0), C.c_double(t0), C.c_double(tf), C.c_double(dt), _p(u), _p(v)
+        C.c_double(p0), C.c_double(s0), C.c_double(t0), C.c_double(tf), C.c_double(dt), _p(u), _p(v),
+        C.c_double(source_scale)
     )
 
 

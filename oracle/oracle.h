@@ -114,6 +114,13 @@ void orc_dphi(int N, const double* nodes, double* D);
                               const REAL* src, const REAL* absb, const REAL* src2, double freq,    \
                               double p0, double s0, double t0, double tf, double dt, REAL* u,      \
                               REAL* v);                                                            \
+  /* same with the source scaling explicit: 2 = Lossy.hpp:216-220, 1 = python _lossy.py:186-189 */  \
+  int64_t orc_lossy_rk4_s_##SUF(int tdim, int64_t ncells, int64_t ndofs, int N,                    \
+                                const int32_t* tensor_dofmap, const REAL* G, const REAL* dphi,     \
+                                const REAL* lin_coeff, const REAL* att_coeff, const REAL* m,       \
+                                const REAL* src, const REAL* absb, const REAL* src2, double freq,  \
+                                double p0, double s0, double t0, double tf, double dt, REAL* u,    \
+                                REAL* v, double source_scale);                                     \
   /* Westervelt.hpp:196-373 (f1 :216-281): lossy f1 + per-stage LHS m = m0 + M(nlin1) u_n and     \
    * RHS term M(nlin2)(v_n^2), both through the mass operator; see oracle_impl.h. */               \
   int64_t orc_westervelt_rk4_##SUF(                                                                \
@@ -122,6 +129,12 @@ void orc_dphi(int N, const double* nodes, double* D);
       const REAL* nlin1_coeff, const REAL* nlin2_coeff, const REAL* m0, const REAL* src,           \
       const REAL* absb, const REAL* src2, double freq, double p0, double s0, double t0, double tf, \
       double dt, REAL* u, REAL* v);                                                                \
+  int64_t orc_westervelt_rk4_s_##SUF(                                                              \
+      int tdim, int64_t ncells, int64_t ndofs, int N, const int32_t* tensor_dofmap, const REAL* G, \
+      const REAL* detJ, const REAL* dphi, const REAL* lin_coeff, const REAL* att_coeff,            \
+      const REAL* nlin1_coeff, const REAL* nlin2_coeff, const REAL* m0, const REAL* src,           \
+      const REAL* absb, const REAL* src2, double freq, double p0, double s0, double t0, double tf, \
+      double dt, REAL* u, REAL* v, double source_scale);                                           \
   /* CPU-baseline variant of orc_linear_rk4 (3-D): nslabs threads, one contiguous cell slab each    \
    * (slab_cell_off[nslabs+1]); even/odd slab passes replace the interface scatter_rev. */          \
   int64_t orc_linear_rk4_mt_##SUF(int64_t ncells, int64_t ndofs, int N,                            \

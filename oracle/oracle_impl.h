@@ -663,13 +663,17 @@ int64_t FN(orc_linear_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
  *   b += g src - absb .* v_n + dg src2,
  * src = (1/rho) w_f on tag 1, absb = (1/(rho c)) w_f on every boundary facet,
  * src2 = (delta/(rho c^2)) w_f on tag 1; m includes the (delta/(rho c^3)) w_f boundary term. */
-int64_t FN(orc_lossy_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
-                          const int32_t* tensor_dofmap, const REAL* G, const REAL* dphi,
-                          const REAL* lin_coeff, const REAL* att_coeff, const REAL* m,
-                          const REAL* src, const REAL* absb, const REAL* src2, double freq_,
-                          double p0_, double s0_, double t0, double tf_, double dt_, REAL* u_n,
-                          REAL* v_n)
+/* source_scale: 2 = the live "heterogenous domain" branch of Lossy.hpp:216-220; 1 = the Python
+ * package (python/src/fenicsxfus/_lossy.py:186-189), which also keeps the absorbing and delta-mass
+ * terms on tag 2 only -- that choice is in the vectors the caller passes (absb, m). */
+int64_t FN(orc_lossy_rk4_s)(int tdim, int64_t ncells, int64_t ndofs, int N,
+                            const int32_t* tensor_dofmap, const REAL* G, const REAL* dphi,
+                            const REAL* lin_coeff, const REAL* att_coeff, const REAL* m,
+                            const REAL* src, const REAL* absb, const REAL* src2, double freq_,
+                            double p0_, double s0_, double t0, double tf_, double dt_, REAL* u_n,
+                            REAL* v_n, double source_scale)
 {
+  const REAL two = (REAL)source_scale;
   const REAL freq = (REAL)freq_, p0 = (REAL)p0_, s0 = (REAL)s0_;
   const REAL w0 = (REAL)(2 * M_PI * freq_);
   const REAL period = (REAL)(1.0 / freq_), window_length = (REAL)4.0;
@@ -707,9 +711,9 @@ int64_t FN(orc_lossy_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
         }
         else
           window = 1.0, dwindow = 0.0;
-        const REAL gval = window * (REAL)2.0 * p0 * w0 / s0 * (REAL)cos((double)(w0 * tn));
-        const REAL dgval = dwindow * (REAL)2.0 * p0 * w0 / s0 * (REAL)cos((double)(w0 * tn))
-                           - window * (REAL)2.0 * p0 * w0 * w0 / s0 * (REAL)sin((double)(w0 * tn));
+        const REAL gval = window * two * p0 * w0 / s0 * (REAL)cos((double)(w0 * tn));
+        const REAL dgval = dwindow * two * p0 * w0 / s0 * (REAL)cos((double)(w0 * tn))
+                           - window * two * p0 * w0 * w0 / s0 * (REAL)sin((double)(w0 * tn));
         FN(k_copy)(ndofs, un, uw);
         FN(k_copy)(ndofs, vn, vw);
         for (int64_t k = 0; k < ndofs; ++k)
@@ -742,20 +746,32 @@ int64_t FN(orc_lossy_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
 }
 
 
+int64_t FN(orc_lossy_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
+                          const int32_t* tensor_dofmap, const REAL* G, const REAL* dphi,
+                          const REAL* lin_coeff, const REAL* att_coeff, const REAL* m,
+                          const REAL* src, const REAL* absb, const REAL* src2, double freq_,
+                          double p0_, double s0_, double t0, double tf_, double dt_, REAL* u_n,
+                          REAL* v_n)
+{
+  return FN(orc_lossy_rk4_s)(tdim, ncells, ndofs, N, tensor_dofmap, G, dphi, lin_coeff, att_coeff, m,
+                             src, absb, src2, freq_, p0_, s0_, t0, tf_, dt_, u_n, v_n, 2.0);
+}
+
 /* Westervelt.hpp:196-373: init + rk4 of the nonlinear (Westervelt) model.  f1 (:216-281) is the
  * lossy f1 plus two diagonal mass actions per stage: the LHS is re-assembled as
  * m = m0 + M(nlin1) u_n  (:249-257, nlin1 = -2 beta/(rho^2 c^4), :185) and the RHS gains
  * M(nlin2) (v_n .* v_n)  (:246-247, :263, nlin2 = +2 beta/(rho^2 c^4), :186).  detJ is the scaled
  * Jacobian determinant the mass operator uses (spectral_op.hpp:80-81).  Other arguments as
  * orc_lossy_rk4 (m0 = its m). */
-int64_t FN(orc_westervelt_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
-                               const int32_t* tensor_dofmap, const REAL* G, const REAL* detJ,
-                               const REAL* dphi, const REAL* lin_coeff, const REAL* att_coeff,
-                               const REAL* nlin1_coeff, const REAL* nlin2_coeff, const REAL* m0,
-                               const REAL* src, const REAL* absb, const REAL* src2, double freq_,
-                               double p0_, double s0_, double t0, double tf_, double dt_,
-                               REAL* u_n, REAL* v_n)
+int64_t FN(orc_westervelt_rk4_s)(int tdim, int64_t ncells, int64_t ndofs, int N,
+                                 const int32_t* tensor_dofmap, const REAL* G, const REAL* detJ,
+                                 const REAL* dphi, const REAL* lin_coeff, const REAL* att_coeff,
+                                 const REAL* nlin1_coeff, const REAL* nlin2_coeff, const REAL* m0,
+                                 const REAL* src, const REAL* absb, const REAL* src2, double freq_,
+                                 double p0_, double s0_, double t0, double tf_, double dt_,
+                                 REAL* u_n, REAL* v_n, double source_scale)
 {
+  const REAL two = (REAL)source_scale;
   const REAL freq = (REAL)freq_, p0 = (REAL)p0_, s0 = (REAL)s0_;
   const REAL w0 = (REAL)(2 * M_PI * freq_);
   const REAL period = (REAL)(1.0 / freq_), window_length = (REAL)4.0;
@@ -794,9 +810,9 @@ int64_t FN(orc_westervelt_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
         }
         else
           window = 1.0, dwindow = 0.0;
-        const REAL gval = window * (REAL)2.0 * p0 * w0 / s0 * (REAL)cos((double)(w0 * tn));
-        const REAL dgval = dwindow * (REAL)2.0 * p0 * w0 / s0 * (REAL)cos((double)(w0 * tn))
-                           - window * (REAL)2.0 * p0 * w0 * w0 / s0 * (REAL)sin((double)(w0 * tn));
+        const REAL gval = window * two * p0 * w0 / s0 * (REAL)cos((double)(w0 * tn));
+        const REAL dgval = dwindow * two * p0 * w0 / s0 * (REAL)cos((double)(w0 * tn))
+                           - window * two * p0 * w0 * w0 / s0 * (REAL)sin((double)(w0 * tn));
         FN(k_copy)(ndofs, un, uw);
         FN(k_copy)(ndofs, vn, vw);
         for (int64_t k = 0; k < ndofs; ++k)
@@ -836,6 +852,19 @@ int64_t FN(orc_westervelt_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
   free(u_), free(v_), free(un), free(vn), free(u0), free(v0), free(ku), free(kv), free(b), free(uw),
       free(vw), free(ww), free(m);
   return step;
+}
+
+int64_t FN(orc_westervelt_rk4)(int tdim, int64_t ncells, int64_t ndofs, int N,
+                               const int32_t* tensor_dofmap, const REAL* G, const REAL* detJ,
+                               const REAL* dphi, const REAL* lin_coeff, const REAL* att_coeff,
+                               const REAL* nlin1_coeff, const REAL* nlin2_coeff, const REAL* m0,
+                               const REAL* src, const REAL* absb, const REAL* src2, double freq_,
+                               double p0_, double s0_, double t0, double tf_, double dt_,
+                               REAL* u_n, REAL* v_n)
+{
+  return FN(orc_westervelt_rk4_s)(tdim, ncells, ndofs, N, tensor_dofmap, G, detJ, dphi, lin_coeff,
+                                  att_coeff, nlin1_coeff, nlin2_coeff, m0, src, absb, src2, freq_, p0_,
+                                  s0_, t0, tf_, dt_, u_n, v_n, 2.0);
 }
 
 

@@ -56,14 +56,16 @@ def _link(objs, out, verbose):
     subprocess.check_call(cmd)
 
 
-def build(force: bool = False, verbose: bool = False, dev: bool = False, name: str = "dev", defines=()) -> str:
-    """dev=True: P=4-only iteration build into abl/libfusmi_<name>.so (use with FUSMI_LIB); extra -D
+def build(force: bool = False, verbose: bool = False, dev: bool = False, name: str = "dev", defines=(),
+          degree: int = 4) -> str:
+    """dev=True: one-degree iteration build into abl/libfusmi_<name>.so (use with FUSMI_LIB); extra -D
     flags select experiment variants (never shipped)."""
     objroot = os.path.join(HERE, "_build")
     if dev:
         out = os.path.join(HERE, "..", "abl", f"libfusmi_{name}.so")
         os.makedirs(os.path.dirname(out), exist_ok=True)
-        _link(_compile_units(os.path.join(objroot, name), (4,), ["-DFUS_DEV_BUILD", *defines], verbose), out, verbose)
+        _link(_compile_units(os.path.join(objroot, name), (degree,),
+                             ["-DFUS_DEV_BUILD", f"-DFUS_DEV_DEGREE={degree}", *defines], verbose), out, verbose)
         return out
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
@@ -73,5 +75,6 @@ def build(force: bool = False, verbose: bool = False, dev: bool = False, name: s
 
 if __name__ == "__main__":
     nm = sys.argv[sys.argv.index("--name") + 1] if "--name" in sys.argv else "dev"
+    deg = int(sys.argv[sys.argv.index("--degree") + 1]) if "--degree" in sys.argv else 4
     print(build(force="--force" in sys.argv, verbose="-q" not in sys.argv, dev="--dev" in sys.argv, name=nm,
-                defines=[a for a in sys.argv if a.startswith("-D")]))
+                defines=[a for a in sys.argv if a.startswith("-D")], degree=deg))

@@ -1269,29 +1269,36 @@ FUS_HIDDEN const DegreeImpl* FUS_CAT(fus_degree_impl_, FUS_TU_DEGREE)(int dtype)
   return dtype == FUS_F64 ? &f64 : &f32;
 }
 #else  // main unit: everything from here to the end of the file
-FUS_HIDDEN const DegreeImpl* fus_degree_impl_4(int);
-#ifndef FUS_DEV_BUILD  // developer iteration build: P = 4 only (never shipped; build.py --dev)
+#ifdef FUS_DEV_BUILD  // developer iteration build: ONE degree (never shipped; build.py --dev)
+#ifndef FUS_DEV_DEGREE
+#define FUS_DEV_DEGREE 4
+#endif
+FUS_HIDDEN const DegreeImpl* FUS_CAT(fus_degree_impl_, FUS_DEV_DEGREE)(int);
+static const DegreeImpl* degree_impl(int dtype, int P)
+{
+  return P == FUS_DEV_DEGREE ? FUS_CAT(fus_degree_impl_, FUS_DEV_DEGREE)(dtype) : nullptr;
+}
+#else
 FUS_HIDDEN const DegreeImpl* fus_degree_impl_2(int);
 FUS_HIDDEN const DegreeImpl* fus_degree_impl_3(int);
+FUS_HIDDEN const DegreeImpl* fus_degree_impl_4(int);
 FUS_HIDDEN const DegreeImpl* fus_degree_impl_5(int);
 FUS_HIDDEN const DegreeImpl* fus_degree_impl_6(int);
 FUS_HIDDEN const DegreeImpl* fus_degree_impl_7(int);
-#endif
 static const DegreeImpl* degree_impl(int dtype, int P)
 {
   switch (P)
   {
-  case 4: return fus_degree_impl_4(dtype);
-#ifndef FUS_DEV_BUILD
   case 2: return fus_degree_impl_2(dtype);
   case 3: return fus_degree_impl_3(dtype);
+  case 4: return fus_degree_impl_4(dtype);
   case 5: return fus_degree_impl_5(dtype);
   case 6: return fus_degree_impl_6(dtype);
   case 7: return fus_degree_impl_7(dtype);
-#endif
   default: return nullptr;
   }
 }
+#endif
 #define FUS_DEGREE(d, dtype_, P_)                                                                  \
   const DegreeImpl* d = degree_impl(dtype_, P_);                                                   \
   if (!d)                                                                                          \

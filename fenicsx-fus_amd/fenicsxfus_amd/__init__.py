@@ -2,7 +2,7 @@
 (sum-factorised operators + RK4 stage update + halo exchange).  The compute path is libfusmi.so
 (hand-written HIP for gfx950 behind the C ABI in include/fusmi.h); this package is the host-side
 mirror of the reference's operator/model interface."""
-from . import tables, utils  # noqa: F401
+from . import output, tables, utils  # noqa: F401
 from ._abi import Context, FusError, layout_check  # noqa: F401
 from .mesh import BoxMesh, CellFunction, FacetTags, Function, FunctionSpace, tag_box_boundary  # noqa: F401
 from .models import (LinearSpectralExplicit, LossySpectralExplicit, WesterveltSpectralExplicit,  # noqa: F401

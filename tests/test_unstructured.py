@@ -219,3 +219,34 @@ def test_reference_2d_operator_test_on_its_own_mesh(orc, ref_mesh2d):
     assert np.abs(uo).max() > 0 and rel(un.x.array, uo) < 1e-10 and rel(vn.x.array, vo) < 1e-10
     model.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("binary", [True, False])
+def test_vtu_output_round_trip(ref_mesh2d, tmp_path, binary):
+    """output.write_vtu: sub-cells on the GLL lattice tile every element exactly (areas / volumes add
+    up to the domain's), vertices in VTK order (positive orientation), fields survive the round trip;
+    hexahedra (box, permuted node order), quadrilaterals (the reference's Gmsh mesh)."""
+    from fenicsxfus_amd.output import read_vtu, subcell_connectivity, write_vtu
+    mesh = fa.BoxMesh([0, 0, 0], [1.5, 1.0, 0.8], (3, 2, 2), perturb=0.1)
+    V = fa.FunctionSpace(mesh, 3, node_order=[3, 0, 2, 1])
+    X = V.tabulate_dof_coordinates()
+    u = np.sin(X[:, 0]) * np.cos(X[:, 1]) + X[:, 2]
+    p = str(tmp_path / "box.vtu")
+    write_vtu(p, V, {"u": u, "v": 2 * u}, binary=binary)
+    d = read_vtu(p)
+    assert np.array_equal(d["Points"], X) and np.array_equal(d["u"], u) and np.array_equal(d["v"], 2 * u)
+    conn = d["connectivity"].reshape(-1, 8)
+    assert conn.shape[0] == mesh.num_cells * 27 and np.all(d["types"] == 12)
+    assert np.array_equal(conn, subcell_connectivity(V))
+    c = X[conn]                                   # sub-cell volume by the triple product at vertex 0 (positive)
+    vol0 = np.einsum("ci,ci->c", np.cross(c[:, 1] - c[:, 0], c[:, 3] - c[:, 0]), c[:, 4] - c[:, 0])
+    assert np.all(vol0 > 0)
+    # quadrilaterals: shoelace areas of the sub-cells add up to the unit square
+    qm, _ = ref_mesh2d
+    Vq = HexFunctionSpace(qm, 4)
+    p2 = str(tmp_path / "quad.vtu")
+    write_vtu(p2, Vq, {"w": np.arange(Vq.num_dofs, dtype=np.float64)}, binary=binary)
+    d2 = read_vtu(p2)
+    q = d2["Points"][d2["connectivity"].reshape(-1, 4)][:, :, :2]
+    area = 0.5 * np.abs(sum(q[:, k, 0] * q[:, (k + 1) % 4, 1] - q[:, (k + 1) % 4, 0] * q[:, k, 1] for k in range(4)))
+    assert abs(area.sum() - 1.0) < 1e-12 and np.all(d2["types"] == 9) and len(area) == 265 * 16

@@ -486,8 +486,13 @@ static int ensure_stream_geometry(fus_op* op)
   const int Nd = op->Nd, ng = op->tdim == 3 ? 6 : 3;
   FUSCHK(dalloc_bytes(op->allocs, &op->d_G, (size_t)op->ncells * ng * Nd * sizeof(T), false, st));
   FUSCHK(dalloc_bytes(op->allocs, &op->d_detJ, (size_t)op->ncells * Nd * sizeof(T), false, st));
-  if (op->tdim == 2)
-    hipLaunchKernelGGL((k_geometry2d<T, N>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st,
+  if (op->tdim == 2 && op->geom_order == 1)
+    hipLaunchKernelGGL((k_geometry2d<T, N, 1>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st,
+                       op->ncells, op->d_cell_perm, static_cast<const T*>(op->d_xg), op->d_xdm,
+                       static_cast<const double*>(op->d_pts), static_cast<const double*>(op->d_wts),
+                       static_cast<T*>(op->d_G), static_cast<T*>(op->d_detJ));
+  else if (op->tdim == 2)
+    hipLaunchKernelGGL((k_geometry2d<T, N, 2>), dim3(nblk(op->ncells * Nd)), dim3(256), 0, st,
                        op->ncells, op->d_cell_perm, static_cast<const T*>(op->d_xg), op->d_xdm,
                        static_cast<const double*>(op->d_pts), static_cast<const double*>(op->d_wts),
                        static_cast<T*>(op->d_G), static_cast<T*>(op->d_detJ));
@@ -700,16 +705,20 @@ static void facet_diag_host(const fus_op* op, int64_t nfacets, const int32_t* fc
     {
       const int64_t cell = fc[f];
       const int ax = axis2[fl[f]], sd = side2[fl[f]], d1 = 1 - ax;
-      T cd[4][3];
-      for (int v = 0; v < 4; ++v)
+      T cd[9][3];
+      const int nv2 = op->geom_nv;
+      for (int v = 0; v < nv2; ++v)
         for (int j = 0; j < 3; ++j)
-          cd[v][j] = xg[3 * (int64_t)op->h_geom_dm[cell * 4 + v] + j];
+          cd[v][j] = xg[3 * (int64_t)op->h_geom_dm[cell * nv2 + v] + j];
       for (int a = 0; a < N; ++a)
       {
         int idx[2];
         idx[ax] = sd ? i_hi : i_lo, idx[d1] = a;
         T J[2][2];
-        jacobian2<T>(cd, op->nodes[idx[0]], op->nodes[idx[1]], J);
+        if (op->geom_order == 1)
+          jacobian2<T>(reinterpret_cast<const T(*)[3]>(cd), op->nodes[idx[0]], op->nodes[idx[1]], J);
+        else
+          jacobian2_q2<T>(cd, op->nodes[idx[0]], op->nodes[idx[1]], J);
         const T len = (T)std::sqrt((double)(J[0][d1] * J[0][d1] + J[1][d1] * J[1][d1]));
         out[op->h_dofmap[cell * Nd + idx[0] * N + idx[1]]] += cellcoef[cell] * len * (T)op->wts[a];
       }
@@ -1616,14 +1625,12 @@ int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_
     return fail(FUS_ERR_ARG, "null argument");
   if (tdim != 2 && tdim != 3)
     return fail(FUS_ERR_ARG, "tdim must be 3 (hexahedra) or 2 (quadrilaterals)");
-  if (tdim == 2 && geom_order != 1)
-    return fail(FUS_ERR_ARG, "quadrilateral meshes need first-order (4-vertex) geometry");
   if (P < 2 || P > 7)
     return fail(FUS_ERR_ARG, "unsupported polynomial degree (2..7)");
   if (dtype != FUS_F64 && dtype != FUS_F32)
     return fail(FUS_ERR_ARG, "dtype must be FUS_F32 or FUS_F64");
   if (geom_order != 1 && geom_order != 2)
-    return fail(FUS_ERR_ARG, "geometry order must be 1 (8 vertices) or 2 (27 nodes, tensor order)");
+    return fail(FUS_ERR_ARG, "geometry order must be 1 (2^tdim vertices) or 2 (3^tdim nodes, tensor order)");
   if (ncells <= 0 || ndofs <= 0 || nnodes <= 0)
     return fail(FUS_ERR_ARG, "empty mesh");
   const int N = P + 1;
@@ -1642,7 +1649,8 @@ int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_
   op->D = dphi_table(N, nodes1d);
   op->h_geom_x.assign(static_cast<const char*>(geom_x),
                       static_cast<const char*>(geom_x) + (size_t)nnodes * 3 * op->ts);
-  op->geom_order = geom_order, op->geom_nv = geom_order == 2 ? 27 : (tdim == 3 ? 8 : 4);
+  op->geom_order = geom_order;
+  op->geom_nv = geom_order == 2 ? (tdim == 3 ? 27 : 9) : (tdim == 3 ? 8 : 4);
   op->h_geom_dm.assign(geom_dofmap, geom_dofmap + ncells * op->geom_nv);
   op->h_dofmap.assign(tensor_dofmap, tensor_dofmap + ncells * op->Nd);
   for (int64_t k = 0; k < ncells * op->geom_nv; ++k)

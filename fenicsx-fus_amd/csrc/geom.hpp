@@ -119,6 +119,32 @@ FUS_HD inline void jacobian2(const T cd[4][3], double X0, double X1, T J[2][2])
   }
 }
 
+// Second-order (9-node, biquadratic) quadrilateral: nodes in tensor order n = nx + 3 ny, n_d in
+// {0,1,2} <-> reference coordinate {0, 1/2, 1} (the `mesh_2` fixture of the naive 2-D operator test).
+template <typename T>
+FUS_HD inline void jacobian2_q2(const T cd[9][3], double X0, double X1, T J[2][2])
+{
+  const double X[2] = {X0, X1};
+  T l[2][3], dl[2][3];
+  for (int d = 0; d < 2; ++d)
+  {
+    const double x = X[d];
+    l[d][0] = (T)((2.0 * x - 1.0) * (x - 1.0)), dl[d][0] = (T)(4.0 * x - 3.0);
+    l[d][1] = (T)(4.0 * x * (1.0 - x)), dl[d][1] = (T)(4.0 - 8.0 * x);
+    l[d][2] = (T)(x * (2.0 * x - 1.0)), dl[d][2] = (T)(4.0 * x - 1.0);
+  }
+  J[0][0] = J[0][1] = J[1][0] = J[1][1] = 0;
+  for (int ny = 0; ny < 3; ++ny)
+    for (int nx = 0; nx < 3; ++nx)
+    {
+      const int n = nx + 3 * ny;
+      const T g[2] = {dl[0][nx] * l[1][ny], l[0][nx] * dl[1][ny]};
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+          J[i][j] += cd[n][i] * g[j];
+    }
+}
+
 // G3 = (xx, xy, yy) of K K^T |det J| w; returns |det J| w
 template <typename T>
 FUS_HD inline T geometric_factor2(const T J[2][2], T w, T G3[3])

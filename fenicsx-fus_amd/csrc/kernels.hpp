@@ -973,14 +973,16 @@ __global__ void k_geometry_affine(int64_t ncells, const int32_t* __restrict__ ce
 }
 
 // Quadrilateral cells: G[e][3][N^2] (xx, xy, yy planes) and detJw[e][N^2] for internal element e
-// (cpp/fenicsx-sf-naive/common/precompute.hpp; bilinear geometry, first two coordinates).
-template <typename T, int N>
+// (cpp/fenicsx-sf-naive/common/precompute.hpp; first two coordinates).  GORD = geometry order:
+// 1 (4 vertices, bilinear) or 2 (9 nodes in tensor order, biquadratic).
+template <typename T, int N, int GORD>
 __global__ void k_geometry2d(int64_t ncells, const int32_t* __restrict__ cell_perm,
                              const T* __restrict__ xg, const int32_t* __restrict__ xdofmap,
                              const double* __restrict__ pts, const double* __restrict__ wts,
                              T* __restrict__ G, T* __restrict__ detJ)
 {
   constexpr int Nd = N * N;
+  constexpr int NVG = (GORD == 1) ? 4 : 9;
   const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= ncells * Nd)
     return;
@@ -988,12 +990,15 @@ __global__ void k_geometry2d(int64_t ncells, const int32_t* __restrict__ cell_pe
   const int q = (int)(gid - e * Nd);
   const int bb = q / N, cc = q - bb * N;
   const int64_t cell = cell_perm[e];
-  T cd[4][3];
-  for (int v = 0; v < 4; ++v)
+  T cd[NVG][3];
+  for (int v = 0; v < NVG; ++v)
     for (int j = 0; j < 3; ++j)
-      cd[v][j] = xg[3 * (int64_t)xdofmap[cell * 4 + v] + j];
+      cd[v][j] = xg[3 * (int64_t)xdofmap[cell * NVG + v] + j];
   T J[2][2], G3[3];
-  jacobian2<T>(cd, pts[bb], pts[cc], J);
+  if constexpr (GORD == 1)
+    jacobian2<T>(cd, pts[bb], pts[cc], J);
+  else
+    jacobian2_q2<T>(cd, pts[bb], pts[cc], J);
   const T dw = geometric_factor2<T>(J, (T)(wts[bb] * wts[cc]), G3);
   detJ[e * Nd + q] = dw;
   for (int gi = 0; gi < 3; ++gi)

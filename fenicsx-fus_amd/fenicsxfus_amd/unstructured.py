@@ -34,6 +34,9 @@ _EDGES = np.array([[0, 1], [2, 3], [4, 5], [6, 7], [0, 2], [1, 3], [4, 6], [5, 7
 # (edges): 0: y=0, 1: x=0, 2: x=1, 3: y=1
 VTK_QUAD_TO_TENSOR = np.array([0, 1, 3, 2])
 QUAD_FACET_VERTS = np.array([[0, 1], [0, 2], [1, 3], [2, 3]])
+# 9-node (biquadratic) quadrilateral: VTK order is 4 corners, 4 mid-edge nodes (edges 0-1, 1-2, 2-3,
+# 3-0), centre; tensor order is n = nx + 3 ny
+VTK_QUAD9_TO_TENSOR = np.array([0, 4, 1, 7, 8, 5, 3, 6, 2])
 
 
 class HexMesh:
@@ -49,7 +52,13 @@ class HexMesh:
         if x.shape[1] == 2:                                            # XDMF "XY" geometry
             x = np.hstack([x, np.zeros((x.shape[0], 1))])
         cells = np.ascontiguousarray(cells, dtype=np.int32)
-        assert x.shape[1] == 3 and cells.shape[1] == (1 << self.tdim)
+        self.order = 1 if cells.shape[1] == (1 << self.tdim) else 2
+        assert x.shape[1] == 3 and cells.shape[1] == (self.order + 1) ** self.tdim
+        assert self.order == 1 or self.tdim == 2, "second-order cells: quadrilaterals only"
+        # positions of the 2^tdim corner vertices (v = vx + 2 vy + 4 vz) inside a cell's node list
+        g = self.order + 1
+        self._corners = np.array([sum((((v >> d) & 1) * self.order) * g**d for d in range(self.tdim))
+                                  for v in range(1 << self.tdim)])
         self.dtype = np.dtype(dtype)
         self.geometry = _Geometry(x.astype(self.dtype), cells, 3)
         self.topology = _Topology(self.tdim, cells.shape[0], cells.shape[0])
@@ -60,10 +69,15 @@ class HexMesh:
         return self.geometry.dofmap.shape[0]
 
     def cell_centroids(self):
-        return self._x64[self.geometry.dofmap].mean(axis=1)
+        return self._x64[self.vertex_dofmap].mean(axis=1)
+
+    @property
+    def vertex_dofmap(self):
+        """[ncells, 2^tdim] corner vertices of each cell (the whole node list for first-order cells)."""
+        return self.geometry.dofmap[:, self._corners]
 
     def _facet_keys(self):
-        fv = self.geometry.dofmap[:, self._facet_verts]               # [nc, nfacets, nverts]
+        fv = self.vertex_dofmap[:, self._facet_verts]                 # [nc, nfacets, nverts]
         return np.sort(fv, axis=2).reshape(-1, self._facet_verts.shape[1])
 
     def exterior_facets(self):
@@ -78,10 +92,11 @@ class HexMesh:
         """Tags given per facet as vertex ids (XDMF ``MeshTags`` topology) -> (cell, local facet)
         pairs; only exterior facets are kept (the forms integrate over ``ds``)."""
         cells, lf = self.exterior_facets()
-        keys = np.sort(self.geometry.dofmap[cells][np.arange(len(cells))[:, None], self._facet_verts[lf]], axis=1)
+        keys = np.sort(self.vertex_dofmap[cells][np.arange(len(cells))[:, None], self._facet_verts[lf]], axis=1)
         lut = {tuple(k): i for i, k in enumerate(keys)}
         fc, fl, fv = [], [], []
-        for verts, val in zip(np.sort(np.asarray(facet_vertices), axis=1), np.asarray(values).ravel()):
+        nfv = self._facet_verts.shape[1]          # higher-order facets list their end vertices first (VTK)
+        for verts, val in zip(np.sort(np.asarray(facet_vertices)[:, :nfv], axis=1), np.asarray(values).ravel()):
             i = lut.get(tuple(verts))
             if i is not None:
                 fc.append(cells[i]), fl.append(lf[i]), fv.append(val)
@@ -89,7 +104,7 @@ class HexMesh:
 
     def entity_counts(self):
         """(#vertices used, #edges, #faces, #cells); a quadrilateral mesh has no faces besides its cells."""
-        dm = self.geometry.dofmap
+        dm = self.vertex_dofmap
         nv = len(np.unique(dm))
         ne = len(np.unique(np.sort(dm[:, self._edges].reshape(-1, 2), axis=1), axis=0))
         nf = len(np.unique(self._facet_keys(), axis=0)) if self.tdim == 3 else 0
@@ -97,7 +112,8 @@ class HexMesh:
 
 
 class QuadMesh(HexMesh):
-    """Unstructured first-order quadrilateral mesh (vertices in tensor order v = vx + 2 vy)."""
+    """Unstructured quadrilateral mesh: first-order (4 vertices, tensor order v = vx + 2 vy) or
+    second-order (9 nodes, tensor order n = nx + 3 ny)."""
 
     tdim = 2
     _facet_verts = QUAD_FACET_VERTS
@@ -115,14 +131,22 @@ class HexFunctionSpace:
         pts, _ = tables.gll(N)
         self.nodes1d = pts
         x = mesh._x64
-        cd = x[mesh.geometry.dofmap]                                   # [nc, 2^t, 3]
-        # multilinear shape functions at the N^t tensor nodes, tensor index (i0*N + i1)*N + i2
+        cd = x[mesh.geometry.dofmap]                                   # [nc, (g+1)^t, 3]
+        # tensor Lagrange shape functions of the geometry (order g = 1: multilinear, 2: biquadratic,
+        # node n = sum_d n_d (g+1)^d) at the N^t tensor nodes, tensor index (i0*N + i1)*N + i2
+        g = getattr(mesh, "order", 1)
         grids = np.meshgrid(*([pts] * t), indexing="ij")
-        X = np.stack([g.ravel() for g in grids], axis=1)               # [Nd, t]
-        phi = np.ones((X.shape[0], 1 << t))
-        for v in range(1 << t):
+        X = np.stack([gr.ravel() for gr in grids], axis=1)             # [Nd, t]
+
+        def basis1d(xv):
+            if g == 1:
+                return np.stack([1.0 - xv, xv], axis=1)
+            return np.stack([(2 * xv - 1) * (xv - 1), 4 * xv * (1 - xv), xv * (2 * xv - 1)], axis=1)
+
+        phi = np.ones((X.shape[0], (g + 1) ** t))
+        for n in range((g + 1) ** t):
             for d in range(t):
-                phi[:, v] *= X[:, d] if (v >> d) & 1 else 1.0 - X[:, d]
+                phi[:, n] *= basis1d(X[:, d])[:, (n // (g + 1) ** d) % (g + 1)]
         nodes = np.einsum("qv,cvk->cqk", phi, cd)                      # [nc, Nd, 3]
         self._node_x = nodes
         scale = np.ptp(x, axis=0).max()
@@ -170,8 +194,10 @@ def read_xdmf_mesh(xdmf_path: str, name: str | None = None, dtype=np.float64):
         mesh = HexMesh(x, data(topo.find("DataItem"))[:, VTK_TO_TENSOR], dtype=dtype)
     elif kind == "quadrilateral" and topo.get("NodesPerElement", "4") == "4":
         mesh = QuadMesh(x, data(topo.find("DataItem"))[:, VTK_QUAD_TO_TENSOR], dtype=dtype)
+    elif kind == "quadrilateral_9":
+        mesh = QuadMesh(x, data(topo.find("DataItem"))[:, VTK_QUAD9_TO_TENSOR], dtype=dtype)
     else:
-        raise NotImplementedError("only first-order hexahedral and quadrilateral grids are read")
+        raise NotImplementedError("grids read: first-order hexahedra, first- and second-order quadrilaterals")
     cell_vals, ftags = None, None
     g = grids.get(f"{name}_cells")
     if g is not None:

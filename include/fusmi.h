@@ -93,8 +93,9 @@ int fus_comm_init_local(fus_ctx** ctxs, int n);
  * One object serves both operators (the reference builds one per operator, Lossy.hpp:152-153).
  *   tdim        3 (hexahedra) or 2 (quadrilaterals: StiffnessSpectral2D / MassSpectral2D,
  *               cpp/fenicsx-sf-naive/common/spectral_op.hpp:29-107, 226-359; N^2 nodes per cell,
- *               geom_dofmap int32[ncells * 4] with v = vx + 2vy, geom_order 1 only, G has 3 entries
- *               (xx, xy, yy) per point, local facets 0..3 = y=0, x=0, x=1, y=1)
+ *               geom_dofmap int32[ncells * 4] with v = vx + 2vy (order 1) or int32[ncells * 9] with
+ *               n = nx + 3ny (order 2, biquadratic), G has 3 entries (xx, xy, yy) per point, local
+ *               facets 0..3 = y=0, x=0, x=1, y=1)
  *   P           polynomial degree 2..7; N = P+1 nodes per direction
  *   dtype       FUS_F64 | FUS_F32: type of geom_x and of every vector/coefficient argument later
  *   tensor_dofmap  int32[ncells * N^tdim], local DOF indices < ndofs, x-slowest tensor order

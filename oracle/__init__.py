@@ -115,8 +115,8 @@ def geometry(tdim, xg, xdofmap, pts, wts, dtype=np.float64):
     ng = 6 if tdim == 3 else 3
     G = np.empty((nc, Nd, ng), dtype=dtype)
     detJ = np.empty((nc, Nd), dtype=dtype)
-    if xd.shape[1] == 27:       # second-order hexahedra, tensor node order
-        getattr(lib(), "orc_geometry_q2_" + _suf(dtype))(
+    if xd.shape[1] == 27 or (tdim == 2 and xd.shape[1] == 9):   # second-order cells, tensor node order
+        getattr(lib(), ("orc_geometry_q2_" if tdim == 3 else "orc_geometry_q2_2d_") + _suf(dtype))(
             C.c_int64(nc), _p(xg), _p(xd), C.c_int(N), _p(pts), _p(wts), _p(G), _p(detJ))
         return G, detJ
     getattr(lib(), "orc_geometry_" + _suf(dtype))(
@@ -152,8 +152,8 @@ def facet_diag(tdim, facet_cell, facet_local, cellcoef, xg, xdofmap, pts, wts, t
                dtype=np.float64):
     fc, fl = _arr(facet_cell, np.int32), _arr(facet_local, np.int32)
     out = np.zeros(ndofs, dtype=dtype)
-    if np.asarray(xdofmap).shape[1] == 27:
-        getattr(lib(), "orc_facet_diag_q2_" + _suf(dtype))(
+    if np.asarray(xdofmap).shape[1] == 27 or (tdim == 2 and np.asarray(xdofmap).shape[1] == 9):
+        getattr(lib(), ("orc_facet_diag_q2_" if tdim == 3 else "orc_facet_diag_q2_2d_") + _suf(dtype))(
             C.c_int64(len(fc)), _p(fc), _p(fl), _p(_arr(cellcoef, dtype)), _p(_arr(xg, dtype)),
             _p(_arr(xdofmap, np.int32)), C.c_int(len(pts)), _p(_arr(pts, np.float64)), _p(_arr(wts, np.float64)),
             _p(_arr(tensor_dofmap, np.int32)), _p(out))

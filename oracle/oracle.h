@@ -68,6 +68,13 @@ void orc_dphi(int N, const double* nodes, double* D);
                                const int32_t* facet_local, const REAL* cellcoef, const REAL* xg,   \
                                const int32_t* xdofmap, int N, const double* pts,                   \
                                const double* wts, const int32_t* tensor_dofmap, REAL* out);        \
+  /* second-order (9-node) quadrilaterals, nodes in tensor order n = nx + 3 ny */                   \
+  void orc_geometry_q2_2d_##SUF(int64_t ncells, const REAL* xg, const int32_t* xdofmap, int N,      \
+                                const double* pts, const double* wts, REAL* G, REAL* detJ);        \
+  void orc_facet_diag_q2_2d_##SUF(int64_t nfacets, const int32_t* facet_cell,                      \
+                                  const int32_t* facet_local, const REAL* cellcoef, const REAL* xg, \
+                                  const int32_t* xdofmap, int N, const double* pts,                \
+                                  const double* wts, const int32_t* tensor_dofmap, REAL* out);     \
   /* spectral_op.hpp:69-86 (+ mass::transform :19-26);  y += M(coeffs) x  (2-D: naive :61-83) */   \
   void orc_mass_##SUF(int tdim, int64_t ncells, int N, const int32_t* tensor_dofmap,               \
                       const REAL* detJ, const REAL* coeffs, const REAL* x, REAL* y);               \

@@ -296,6 +296,100 @@ void FN(orc_facet_diag_q2)(int64_t nfacets, const int32_t* facet_cell, const int
   }
 }
 
+/* Second-order (9-node, biquadratic) quadrilaterals: the 2-D counterpart of jac3_q2 for the
+ * reference's `mesh_2` fixture of cpp/fenicsx-sf-naive/tests/test_operators2d (main.cpp:31, G = 2).
+ * Nodes in tensor order n = nx + 3 ny, n_d in {0,1,2} <-> X_d in {0,1/2,1}. */
+static void FN(jac2_q2)(const REAL cd[9][3], double X0, double X1, REAL J[2][2])
+{
+  const double X[2] = {X0, X1};
+  REAL l[2][3], dl[2][3];
+  for (int d = 0; d < 2; ++d)
+  {
+    const double x = X[d];
+    l[d][0] = (REAL)((2.0 * x - 1.0) * (x - 1.0)), dl[d][0] = (REAL)(4.0 * x - 3.0);
+    l[d][1] = (REAL)(4.0 * x * (1.0 - x)), dl[d][1] = (REAL)(4.0 - 8.0 * x);
+    l[d][2] = (REAL)(x * (2.0 * x - 1.0)), dl[d][2] = (REAL)(4.0 * x - 1.0);
+  }
+  J[0][0] = J[0][1] = J[1][0] = J[1][1] = 0;
+  for (int ny = 0; ny < 3; ++ny)
+    for (int nx = 0; nx < 3; ++nx)
+    {
+      const int n = nx + 3 * ny;
+      const REAL g[2] = {dl[0][nx] * l[1][ny], l[0][nx] * dl[1][ny]};
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
+          J[i][j] += cd[n][i] * g[j];
+    }
+}
+
+void FN(orc_geometry_q2_2d)(int64_t ncells, const REAL* xg, const int32_t* xdofmap, int N,
+                            const double* pts, const double* wts, REAL* G, REAL* detJ)
+{
+  const int Nd = N * N;
+  for (int64_t c = 0; c < ncells; ++c)
+  {
+    REAL cd[9][3];
+    for (int v = 0; v < 9; ++v)
+      for (int j = 0; j < 3; ++j)
+        cd[v][j] = xg[3 * (int64_t)xdofmap[c * 9 + v] + j];
+    for (int q0 = 0; q0 < N; ++q0)
+      for (int q1 = 0; q1 < N; ++q1)
+      {
+        const int q = q0 * N + q1;
+        const REAL w = (REAL)(wts[q0] * wts[q1]);
+        REAL J[2][2], K[2][2];
+        FN(jac2_q2)(cd, pts[q0], pts[q1], J);
+        const REAL det = J[0][0] * J[1][1] - J[0][1] * J[1][0];
+        K[0][0] = J[1][1] / det, K[0][1] = -J[0][1] / det, K[1][0] = -J[1][0] / det, K[1][1] = J[0][0] / det;
+        const REAL dw = (REAL)fabs((double)det) * w;
+        if (detJ)
+          detJ[c * Nd + q] = dw;
+        if (G)
+        {
+          REAL* g = G + (c * Nd + q) * 3;
+          g[0] = dw * (K[0][0] * K[0][0] + K[0][1] * K[0][1]);
+          g[1] = dw * (K[0][0] * K[1][0] + K[0][1] * K[1][1]);
+          g[2] = dw * (K[1][0] * K[1][0] + K[1][1] * K[1][1]);
+        }
+      }
+  }
+}
+
+void FN(orc_facet_diag_q2_2d)(int64_t nfacets, const int32_t* facet_cell, const int32_t* facet_local,
+                              const REAL* cellcoef, const REAL* xg, const int32_t* xdofmap, int N,
+                              const double* pts, const double* wts, const int32_t* tensor_dofmap,
+                              REAL* out)
+{
+  static const int axis2[4] = {1, 0, 0, 1}, side2[4] = {0, 0, 1, 1};
+  const int Nd = N * N;
+  int i_lo = 0, i_hi = 0;
+  for (int i = 0; i < N; ++i)
+  {
+    if (pts[i] < pts[i_lo])
+      i_lo = i;
+    if (pts[i] > pts[i_hi])
+      i_hi = i;
+  }
+  for (int64_t f = 0; f < nfacets; ++f)
+  {
+    const int64_t c = facet_cell[f];
+    const int ax = axis2[facet_local[f]], sd = side2[facet_local[f]], d1 = 1 - ax;
+    REAL cd[9][3];
+    for (int v = 0; v < 9; ++v)
+      for (int j = 0; j < 3; ++j)
+        cd[v][j] = xg[3 * (int64_t)xdofmap[c * 9 + v] + j];
+    for (int a = 0; a < N; ++a)
+    {
+      int idx[2];
+      idx[ax] = sd ? i_hi : i_lo, idx[d1] = a;
+      REAL J[2][2];
+      FN(jac2_q2)(cd, pts[idx[0]], pts[idx[1]], J);
+      const REAL len = (REAL)sqrt((double)(J[0][d1] * J[0][d1] + J[1][d1] * J[1][d1]));
+      out[tensor_dofmap[c * Nd + idx[0] * N + idx[1]]] += cellcoef[c] * len * (REAL)wts[a];
+    }
+  }
+}
+
 /* spectral_op.hpp:69-86 with mass::transform :19-26 (identical in the naive 2-D class) */
 void FN(orc_mass)(int tdim, int64_t ncells, int N, const int32_t* tensor_dofmap, const REAL* detJ,
                   const REAL* coeffs, const REAL* x, REAL* y)

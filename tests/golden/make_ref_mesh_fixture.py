@@ -38,3 +38,17 @@ np.savez_compressed(
     facet_values=f2["/MeshTags/quad_facets/Values"].ravel().astype(np.int32),
 )
 print("wrote ref_test_operators2d_mesh.npz")
+
+# ... and its second-order twin (mesh_2: the same 265 quadrilaterals with 9 nodes each, G = 2 in
+# main.cpp:31), data only.
+src3 = "/root/reference/cpp/fenicsx-sf-naive/tests/test_operators2d/mesh_2/mesh.h5"
+f3 = H5File(src3)
+np.savez_compressed(
+    os.path.join(HERE, "ref_test_operators2d_mesh2.npz"),
+    geometry=f3["/Mesh/quad/geometry"],
+    topology_vtk=f3["/Mesh/quad/topology"].astype(np.int32),
+    cell_values=f3["/MeshTags/quad_cells/Values"].ravel().astype(np.int32),
+    facet_topology=f3["/MeshTags/quad_facets/topology"].astype(np.int32),
+    facet_values=f3["/MeshTags/quad_facets/Values"].ravel().astype(np.int32),
+)
+print("wrote ref_test_operators2d_mesh2.npz")

@@ -250,3 +250,100 @@ def test_vtu_output_round_trip(ref_mesh2d, tmp_path, binary):
     q = d2["Points"][d2["connectivity"].reshape(-1, 4)][:, :, :2]
     area = 0.5 * np.abs(sum(q[:, k, 0] * q[:, (k + 1) % 4, 1] - q[:, (k + 1) % 4, 0] * q[:, k, 1] for k in range(4)))
     assert abs(area.sum() - 1.0) < 1e-12 and np.all(d2["types"] == 9) and len(area) == 265 * 16
+
+
+# ---- second-order (9-node) quadrilaterals: the naive 2-D operator test's mesh_2 -----------------------
+GOLD2B = os.path.join(os.path.dirname(__file__), "golden", "ref_test_operators2d_mesh2.npz")
+REF_XDMF2B = "/root/reference/cpp/fenicsx-sf-naive/tests/test_operators2d/mesh_2/mesh.xdmf"
+
+
+def _q2_mesh(curved=0.0, seed=0):
+    """mesh_2 of the reference's 2-D operator test; curved > 0 moves the interior mid-edge and centre
+    nodes by that fraction of the local cell size (the same offset for both cells sharing an edge),
+    which makes the cells genuinely biquadratic."""
+    from fenicsxfus_amd.unstructured import VTK_QUAD9_TO_TENSOR, QuadMesh
+    g = np.load(GOLD2B)
+    x = g["geometry"].copy()
+    cells = g["topology_vtk"][:, VTK_QUAD9_TO_TENSOR]
+    if curved:
+        rng = np.random.default_rng(seed)
+        corner = np.zeros(len(x), bool)
+        corner[np.unique(cells[:, [0, 2, 6, 8]])] = True
+        onb = (np.abs(x - 0.5).max(axis=1) > 0.5 - 1e-12)
+        h = np.sqrt(1.0 / len(cells))
+        move = ~corner & ~onb
+        x[move] += curved * h * rng.uniform(-1, 1, (move.sum(), 2))
+    mesh = QuadMesh(x, cells)
+    return mesh, mesh.facet_tags(g["facet_topology"], g["facet_values"])
+
+
+def test_second_order_quads_reader_and_oracle(orc, ref_mesh2d):
+    mesh, tags = _q2_mesh()
+    if os.path.exists(REF_XDMF2B):
+        m2, cv, t2 = fa.read_xdmf_mesh(REF_XDMF2B)
+        assert m2.order == 2 and np.array_equal(m2.geometry.dofmap, mesh.geometry.dofmap)
+        assert len(cv) == 265 and np.array_equal(t2.cells, tags.cells)
+    assert mesh.order == 2 and mesh.geometry.dofmap.shape == (265, 9) and len(tags.cells) == 60
+    assert mesh.entity_counts() == (296, 560, 0, 265)
+    V = HexFunctionSpace(mesh, 4)
+    wts = orc.gll_weights_at(V.nodes1d)
+    G, dJ = orc.geometry(2, mesh.geometry.x, mesh.geometry.dofmap, V.nodes1d, wts)
+    # the file's second-order cells are straight-sided: same factors as the first-order twin mesh_1
+    m1, _ = ref_mesh2d
+    G1, dJ1 = orc.geometry(2, m1.geometry.x, m1.geometry.dofmap, V.nodes1d, wts)
+    assert np.abs(G - G1).max() < 1e-11 and np.abs(dJ - dJ1).max() < 1e-14
+    # curved cells: area and perimeter are still those of the unit square (interior nodes moved only)
+    mc, tc = _q2_mesh(curved=0.05)
+    Vc = HexFunctionSpace(mc, 5)
+    wc, Dc = orc.gll_weights_at(Vc.nodes1d), orc.dphi(Vc.nodes1d)
+    Gc, dJc = orc.geometry(2, mc.geometry.x, mc.geometry.dofmap, Vc.nodes1d, wc)
+    assert np.abs(Gc - orc.geometry(2, m1.geometry.x, m1.geometry.dofmap, Vc.nodes1d, wc)[0]).max() > 1e-3
+    assert abs(dJc.sum() - 1.0) < 1e-12 and dJc.min() > 0
+    n, nc = Vc.num_dofs, mc.num_cells
+    per = orc.facet_diag(2, tc.cells, tc.local_facets, np.ones(nc), mc.geometry.x, mc.geometry.dofmap, Vc.nodes1d, wc,
+                         Vc.tensor_dofmap, n).sum()
+    assert abs(per - 4.0) < 1e-12
+    K = lambda v: orc.stiffness(2, 6, Vc.tensor_dofmap, Gc, Dc, np.ones(nc), v, np.zeros(n))  # noqa: E731
+    assert np.abs(K(np.ones(n))).max() < 1e-12
+    X = Vc.tabulate_dof_coordinates()
+    for d in (0, 1):    # the coordinate functions are in the isoparametric space: energy = area
+        assert abs(X[:, d] @ K(X[:, d].copy()) - 1.0) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("curved", [0.0, 0.05])
+def test_second_order_quads_gpu(orc, curved):
+    """The naive 2-D operator test with G = 2 (main.cpp:31) on its mesh_2, and on a curved variant:
+    HIP operators, geometry and 10 Linear RK4 steps against the oracle."""
+    mesh, tags = _q2_mesh(curved=curved)
+    P = 4
+    V = HexFunctionSpace(mesh, P)
+    n, nc = V.num_dofs, mesh.num_cells
+    wts, D = orc.gll_weights_at(V.nodes1d), orc.dphi(V.nodes1d)
+    G, dJ = orc.geometry(2, mesh.geometry.x, mesh.geometry.dofmap, V.nodes1d, wts)
+    ctx = fa.Context(0)
+    d = fa.SpectralOperatorData(V, ctx)
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()  # noqa: E731
+    Gd, dJd = d.geometry()
+    assert rel(Gd, G) < 1e-12 and rel(dJd, dJ) < 1e-13
+    for kind, x, coef in _recipe2d(V, nc):
+        if kind == "mass":
+            assert rel(d.mass(x, coef, np.zeros(n)), orc.mass(2, P + 1, V.tensor_dofmap, dJ, coef, x, np.zeros(n))) < 1e-14
+        else:
+            assert rel(d.stiffness(x, coef, np.zeros(n)),
+                       orc.stiffness(2, P + 1, V.tensor_dofmap, G, D, coef, x, np.zeros(n))) < 1e-12
+    d.close()
+    c, rho = np.full(nc, 1500.0), np.full(nc, 1000.0)
+    m = orc.mass(2, P + 1, V.tensor_dofmap, dJ, 1 / (rho * c * c), np.ones(n), np.zeros(n))
+    src = orc.facet_diag(2, tags.cells, tags.local_facets, 1 / rho, mesh.geometry.x, mesh.geometry.dofmap, V.nodes1d,
+                         wts, V.tensor_dofmap, n)
+    dt = 0.1 * np.sqrt(dJ.reshape(nc, -1).sum(axis=1)).min() / (1500.0 * P**2)
+    uo, vo = np.zeros(n), np.zeros(n)
+    orc.linear_rk4(2, P + 1, V.tensor_dofmap, G, D, -1 / rho, m, src, np.zeros(n), 5e3, 6e4, 1500.0, 0.0,
+                   10 * dt * (1 - 1e-9), dt, uo, vo)
+    model = fa.LinearSpectralExplicit(mesh, tags, P, c, rho, 5e3, 6e4, 1500.0, 4, dt, V=V, ctx=ctx)
+    model.init()
+    un, vn, _ = model.rk(0.0, 10 * dt * (1 - 1e-9))
+    assert np.abs(uo).max() > 0 and rel(un.x.array, uo) < 1e-10 and rel(vn.x.array, vo) < 1e-10
+    model.close()
+    ctx.close()

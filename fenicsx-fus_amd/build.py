@@ -25,6 +25,7 @@ def _compile_units(objdir, degrees, extra, verbose):
     from concurrent.futures import ThreadPoolExecutor
 
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    extra = [*extra, *os.environ.get("FUSMI_EXTRA_FLAGS", "").split()]   # compiler-flag experiments
     os.makedirs(objdir, exist_ok=True)
     jobs = [([hipcc, *FLAGS, *extra, "-c", SRC[0], "-o", os.path.join(objdir, "fusmi_main.o")]),
             ([hipcc, *FLAGS, *extra, "-c", SRC[1], "-o", os.path.join(objdir, "layout.o")])]

@@ -1734,10 +1734,18 @@ int fus_op_info(fus_op* op, int64_t out[8])
 int fus_layout_check(int P, int64_t ncells, int64_t ndofs, const int32_t* tensor_dofmap,
                      const double* centroids, int block_elems, int waves, int64_t out[8])
 {
+  return fus_layout_check_ex(3, P, ncells, ndofs, tensor_dofmap, centroids, block_elems, waves, nullptr, out);
+}
+
+int fus_layout_check_ex(int tdim, int P, int64_t ncells, int64_t ndofs, const int32_t* tensor_dofmap,
+                        const double* centroids, int block_elems, int waves,
+                        const uint8_t* force_shared, int64_t out[8])
+{
   if (!tensor_dofmap || !centroids || !out)
     return fail(FUS_ERR_ARG, "null argument");
   Layout L;
-  std::string err = build_layout(L, P, ncells, ndofs, tensor_dofmap, centroids, block_elems, waves);
+  std::string err = build_layout(L, P, ncells, ndofs, tensor_dofmap, centroids, block_elems, waves,
+                                 force_shared, tdim);
   if (!err.empty())
     return fail(FUS_ERR_ARG, "layout: " + err);
   err = verify_layout(L, tensor_dofmap);

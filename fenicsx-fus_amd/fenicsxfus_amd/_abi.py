@@ -22,7 +22,7 @@ SYMBOLS = [
     "fus_mass_apply", "fus_op_get_geometry", "fus_op_get_tables", "fus_op_info", "fus_op_is_affine", "fus_facet_diag",
     "fus_op_set_neighbours", "fus_model_create", "fus_model_destroy", "fus_model_set_rk_order", "fus_model_init", "fus_model_rk4",
     "fus_model_rk4_steps", "fus_model_get", "fus_model_set", "fus_model_get_mass", "fus_model_ndofs",
-    "fus_profile_enable", "fus_profile_get", "fus_layout_check", "fus_comm_init_local",
+    "fus_profile_enable", "fus_profile_get", "fus_layout_check", "fus_layout_check_ex", "fus_comm_init_local",
     "fus_group_finish_setup", "fus_group_rk4_steps",
 ]
 
@@ -139,11 +139,19 @@ class Context:
             self.h = C.c_void_p()
 
 
-def layout_check(P, tensor_dofmap, centroids, block_elems=64, waves=4):
-    """Host-only: run the block partitioner + verifier; returns the 8 statistics of fus_op_info."""
+def layout_check(P, tensor_dofmap, centroids, block_elems=64, waves=4, tdim=None, force_shared=None):
+    """Host-only: run the block partitioner + verifier; returns the 8 statistics of fus_op_info.
+    tdim defaults to what the dofmap width says; force_shared: optional bool mask of interface dofs."""
     dm = np.ascontiguousarray(tensor_dofmap, dtype=np.int32)
+    if tdim is None:
+        tdim = 3 if dm.shape[1] == (P + 1) ** 3 else 2
     cen = np.ascontiguousarray(centroids, dtype=np.float64)
+    if cen.shape[1] == 2:
+        cen = np.hstack([cen, np.zeros((cen.shape[0], 1))])
+    ndofs = int(dm.max()) + 1
+    fs = None if force_shared is None else np.ascontiguousarray(force_shared, dtype=np.uint8)
+    assert fs is None or fs.shape[0] == ndofs
     out = (C.c_int64 * 8)()
-    check(lib().fus_layout_check(C.c_int(P), C.c_int64(dm.shape[0]), C.c_int64(int(dm.max()) + 1), ptr(dm),
-                                 ptr(cen), C.c_int(block_elems), C.c_int(waves), out))
+    check(lib().fus_layout_check_ex(C.c_int(tdim), C.c_int(P), C.c_int64(dm.shape[0]), C.c_int64(ndofs), ptr(dm),
+                                    ptr(cen), C.c_int(block_elems), C.c_int(waves), ptr(fs), out))
     return list(out)

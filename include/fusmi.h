@@ -208,6 +208,12 @@ int fus_profile_get(fus_ctx* ctx, const char* name, double* total_ms, int64_t* c
 int fus_layout_check(int P, int64_t ncells, int64_t ndofs, const int32_t* tensor_dofmap,
                      const double* centroids /* [ncells*3] */, int block_elems, int waves,
                      int64_t out[8]);
+/* The same for tdim = 2 | 3 and with the optional mask of DOFs other ranks hold as well
+ * (force_shared, uint8[ndofs] or NULL): those DOFs are classified shared and the blocks touching
+ * them come first in the layout (fus_op_set_neighbours does this on the device path). */
+int fus_layout_check_ex(int tdim, int P, int64_t ncells, int64_t ndofs, const int32_t* tensor_dofmap,
+                        const double* centroids, int block_elems, int waves,
+                        const uint8_t* force_shared, int64_t out[8]);
 
 #ifdef __cplusplus
 }

@@ -68,6 +68,31 @@ def test_layout_structured_box_is_cubic_blocks():
     assert info[0] == 64 and info[5] == 27
 
 
+@pytest.mark.parametrize("n,P,be", [((9, 7), 4, 16), ((23, 17), 2, 100), ((5, 4), 7, 6)])
+def test_layout_invariants_quadrilaterals(n, P, be):
+    m = fa.BoxMesh([0, 0], [1.5, 1.0], n, perturb=0.1)
+    V = fa.FunctionSpace(m, P)
+    nblocks, nint, nsh, npairs, maxloc, nshapes, lds, nintl = fa.layout_check(P, V.tensor_dofmap, m.cell_centroids(),
+                                                                               block_elems=be, waves=2)
+    assert nint + nsh == V.num_dofs and nblocks == -(-m.num_cells // be) and nintl % 16 == 0
+
+
+def test_layout_interface_mask_forces_shared():
+    """Multi-rank layout: dofs on the slab's interface plane (held by the neighbour rank too) are
+    classified shared even where a single local block touches them."""
+    m = fa.BoxMesh([0, 0, 0], [2, 1, 1], (8, 4, 4), rank=0, size=2)
+    V = fa.FunctionSpace(m, 3)
+    mask = np.zeros(V.num_dofs, bool)
+    for _, idx in V.neighbours:
+        mask[idx] = True
+    assert mask.sum() == (4 * 3 + 1) ** 2
+    base = fa.layout_check(3, V.tensor_dofmap, m.cell_centroids(), block_elems=16)
+    forced = fa.layout_check(3, V.tensor_dofmap, m.cell_centroids(), block_elems=16, force_shared=mask)
+    assert base[1] + base[2] == V.num_dofs
+    # shared count includes the alignment gap before the interface range, hence >=
+    assert forced[1] < base[1] and forced[1] + forced[2] >= V.num_dofs and forced[0] == base[0]
+
+
 def test_layout_rejects_bad_dofmap():
     m = fa.BoxMesh([0, 0, 0], [1, 1, 1], (2, 2, 2))
     V = fa.FunctionSpace(m, 2)

@@ -60,9 +60,11 @@ class _WrappedSpace:
 
 
 def wrap_function_space(V, P: int):
-    """``V``: a ``dolfinx.fem.FunctionSpace`` of degree-P ``gll_warped`` Lagrange on hexahedra."""
+    """``V``: a ``dolfinx.fem.FunctionSpace`` of degree-P ``gll_warped`` Lagrange on hexahedra or
+    quadrilaterals."""
     basix, dolfinx = _require()
-    tp_order = np.asarray(basix.tp_dof_ordering(basix.ElementFamily.P, basix.CellType.hexahedron, P,
+    cell = basix.CellType.hexahedron if V.mesh.topology.dim == 3 else basix.CellType.quadrilateral
+    tp_order = np.asarray(basix.tp_dof_ordering(basix.ElementFamily.P, cell, P,
                                                 basix.LagrangeVariant.gll_warped, basix.DPCVariant.unset, False))
     perm = np.argsort(tp_order, kind="stable")                    # permute.hpp:27-32
     dm = np.asarray(V.dofmap.list).reshape(-1, len(tp_order))
@@ -140,14 +142,28 @@ def hex27_dolfinx_to_tensor():
     return np.array([n[0] + 3 * n[1] + 9 * n[2] for n in nodes], dtype=np.int64)
 
 
+_QUAD_EDGES = [(0, 1), (0, 2), (1, 3), (2, 3)]
+
+
+def quad9_dolfinx_to_tensor():
+    """The same for the 9-node quadrilateral (vertices, edges, interior -> n = nx + 3 ny)."""
+    def pos(v):
+        return np.array([v & 1, v >> 1]) * 2
+    nodes = [pos(v) for v in range(4)]
+    nodes += [(pos(a) + pos(b)) // 2 for a, b in _QUAD_EDGES]
+    nodes.append(np.array([1, 1]))
+    return np.array([n[0] + 3 * n[1] for n in nodes], dtype=np.int64)
+
+
 def tensor_geometry_dofmap(mesh):
     """Geometry dofmap of a DOLFINx mesh in the order libfusmi expects (order 1: unchanged)."""
     gd = np.asarray(mesh.geometry.dofmap)
-    if gd.shape[1] == 8:
+    tdim = mesh.topology.dim
+    if gd.shape[1] == (1 << tdim):
         return gd.astype(np.int32)
-    if gd.shape[1] != 27:
-        raise ValueError("only first- and second-order hexahedral geometry is supported")
-    perm = hex27_dolfinx_to_tensor()
+    if gd.shape[1] != 3 ** tdim:
+        raise ValueError("only first- and second-order hexahedral / quadrilateral geometry is supported")
+    perm = hex27_dolfinx_to_tensor() if tdim == 3 else quad9_dolfinx_to_tensor()
     out = np.empty_like(gd, dtype=np.int32)
     out[:, perm] = gd
     return out

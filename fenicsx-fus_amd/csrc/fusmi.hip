@@ -227,6 +227,12 @@ struct fus_model
   bool setup_done = false;
   int rk_order = 4;  // explicit Runge-Kutta scheme, tables of python/src/fenicsxfus/_linear.py:286-311
   int forms = 0;     // fus_ctx::forms at creation
+  // The boundary term of the shared boundary dofs rides in pseudo partial slots.  With RK4 the
+  // shared-dof stage kernels write the NEXT stage's values there (boundary_next, kernels.hpp);
+  // bnd_valid / bnd_tn say for which stage time the slots are current, and stage_begin launches
+  // k_boundary_partial only when they are not (first stage after init / set, other RK orders).
+  bool bnd_valid = false;
+  double bnd_tn = 0.0;
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -954,6 +960,7 @@ static int model_setup_finish(fus_model* m)
 struct StageScalars
 {
   double gval, dgval, adt, bdt;
+  double tn;  // the stage's time t + c_i dt as the scalars above saw it (in T)
 };
 
 // source scalar g(t_n) (Linear.hpp:185-192) and the stage's axpy factors (:282-294), in T
@@ -1011,6 +1018,7 @@ static StageScalars stage_scalars(const fus_model* m, int i, double t_, double d
   }
   sc.adt = (double)(dt * a_runge[i + 1]);
   sc.bdt = (double)(dt * b_runge[i]);
+  sc.tn = (double)tn;
   return sc;
 }
 
@@ -1086,7 +1094,8 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
   // boundary terms of the shared boundary dofs become one more partial each
   hipStream_t st = m->ctx->stream;
   const int64_t nbs = m->nb - m->nb_int;
-  if (nbs > 0)
+  const StageScalars sc_now = stage_scalars<T>(m, i, t, dt);
+  if (nbs > 0 && !(m->bnd_valid && m->bnd_tn == sc_now.tn))
   {
     ProfScope ps(m->ctx, "boundary");
     hipLaunchKernelGGL((k_boundary_partial<T>), dim3(nblk(nbs)), dim3(256), 0, st, nbs,
@@ -1136,6 +1145,24 @@ static int stage_end(fus_model* m, int i, double t, double dt)
   // Westervelt: m0 and mn1 on the shared range (nullptr otherwise)
   const T* m0p = m->mn1 ? static_cast<const T*>(m->m) + off : nullptr;
   const T* mn1p = m->mn1 ? static_cast<const T*>(m->mn1) + off : nullptr;
+  // RK4: this stage's kernels also leave the next stage's boundary terms of the shared boundary dofs
+  // in their pseudo partial slots (next stage of this step, or stage 0 of the next step at t + dt,
+  // advanced the way the step loops do: in T for fus_model_rk4, whose t is a T)
+  BndNext<T> B{};
+  const int64_t nbs = m->nb - m->nb_int;
+  m->bnd_valid = false;
+  if (m->rk_order == 4 && nbs > 0 && op->L.npairs + nbs < INT32_MAX)
+  {
+    const StageScalars scn = i < 3 ? stage_scalars<T>(m, i + 1, t, dt)
+                                   : stage_scalars<T>(m, 0, (double)((T)t + (T)dt), dt);
+    B.enabled = 1, B.npairs = (int32_t)op->L.npairs;
+    B.srcw = static_cast<const T*>(m->d_bsrc) + m->nb_int;
+    B.absw = static_cast<const T*>(m->d_babs) + m->nb_int;
+    B.src2w = m->d_bsrc2 ? static_cast<const T*>(m->d_bsrc2) + m->nb_int : nullptr;
+    B.gnext = (T)scn.gval, B.dgnext = (T)scn.dgval;
+    B.partial = static_cast<T*>(op->d_partial);
+    m->bnd_valid = true, m->bnd_tn = scn.tn;
+  }
   if (nloc > 0)
   {
     ProfScope ps(c, "stage");
@@ -1145,17 +1172,17 @@ static int stage_end(fus_model* m, int i, double t, double dt)
     case 0:
       hipLaunchKernelGGL((k_shared_stage<T, 0>), grid, blk, 0, st, nloc, m->d_sh_ptr32,
                          m->d_sh_pairs32, partial, minv + off, vn + off, un + off, u0 + off,
-                         v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p);
+                         v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p, B);
       break;
     case 3:
       hipLaunchKernelGGL((k_shared_stage<T, 3>), grid, blk, 0, st, nloc, m->d_sh_ptr32,
                          m->d_sh_pairs32, partial, minv + off, vn + off, un + off, u0 + off,
-                         v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p);
+                         v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p, B);
       break;
     default:
       hipLaunchKernelGGL((k_shared_stage<T, 1>), grid, blk, 0, st, nloc, m->d_sh_ptr32,
                          m->d_sh_pairs32, partial, minv + off, vn + off, un + off, u0 + off,
-                         v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p);
+                         v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p, B);
     }
   }
   if (!op->neigh.empty())
@@ -1174,17 +1201,17 @@ static int stage_end(fus_model* m, int i, double t, double dt)
     case 0:
       hipLaunchKernelGGL((k_if_unpack_stage<T, 0>), grid, blk, 0, st, op->n_uidx, op->d_uidx,
                          op->d_uptr, op->d_usrc, recv, b, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0f,
-                         mn1f);
+                         mn1f, op->L.n_int_pad, m->d_sh_ptr32, m->d_sh_pairs32, B);
       break;
     case 3:
       hipLaunchKernelGGL((k_if_unpack_stage<T, 3>), grid, blk, 0, st, op->n_uidx, op->d_uidx,
                          op->d_uptr, op->d_usrc, recv, b, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0f,
-                         mn1f);
+                         mn1f, op->L.n_int_pad, m->d_sh_ptr32, m->d_sh_pairs32, B);
       break;
     default:
       hipLaunchKernelGGL((k_if_unpack_stage<T, 1>), grid, blk, 0, st, op->n_uidx, op->d_uidx,
                          op->d_uptr, op->d_usrc, recv, b, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0f,
-                         mn1f);
+                         mn1f, op->L.n_int_pad, m->d_sh_ptr32, m->d_sh_pairs32, B);
     }
   }
   HIPCHK(hipGetLastError());
@@ -1992,6 +2019,7 @@ int fus_model_set_rk_order(fus_model* m, int order)
   if (!m || order < 1 || order > 4)
     return fail(FUS_ERR_ARG, "rk order must be 1, 2, 3 or 4");
   m->rk_order = order;
+  m->bnd_valid = false;
   return FUS_OK;
 }
 
@@ -2016,6 +2044,7 @@ int fus_model_init(fus_model* m)
   for (void* v : {m->u0, m->v0, m->u_, m->v_, m->un, m->vn, m->b})
     HIPCHK(hipMemsetAsync(v, 0, bytes, m->ctx->stream));
   m->initialised = true;
+  m->bnd_valid = false;  // state changed: the pseudo boundary partials are stale
   return FUS_OK;
 }
 
@@ -2092,6 +2121,7 @@ int fus_model_set(fus_model* m, int which, const void* in, int space)
     return fail(FUS_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(m->ctx->device));
   m->initialised = true;
+  m->bnd_valid = false;  // state changed: the pseudo boundary partials are stale
   return m->op->dtype == FUS_F64
              ? model_getset<double>(m, which, const_cast<void*>(in), space, true)
              : model_getset<float>(m, which, const_cast<void*>(in), space, true);

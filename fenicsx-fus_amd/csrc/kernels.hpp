@@ -752,7 +752,7 @@ __global__ void k_shared_reduce(int64_t s0, int64_t s1, const I* __restrict__ sh
 // Model vectors are read / written once per stage: non-temporal, so that the partial slab (written
 // just before by k_block_op) stays cache resident.
 template <typename T, int STAGE>
-__device__ __forceinline__ void stage_update_dof(int64_t s, T acc, const T* __restrict__ minv,
+__device__ __forceinline__ T stage_update_dof(int64_t s, T acc, const T* __restrict__ minv,
                                                  T* __restrict__ vn, T* __restrict__ un,
                                                  T* __restrict__ u0, T* __restrict__ v0,
                                                  T* __restrict__ u_, T* __restrict__ v_, T adt, T bdt,
@@ -768,18 +768,21 @@ __device__ __forceinline__ void stage_update_dof(int64_t s, T acc, const T* __re
   }
   else
     kv = acc * FUS_LD(minv);
+  T vnext;  // the velocity the NEXT stage starts from: vn' (stages 0-2) or the new v0 (stage 3)
   if (STAGE == 0)
   {
     const T u = FUS_LD(u0), v = FUS_LD(v0);
     FUS_ST(u_, v * bdt + u);
     FUS_ST(v_, kv * bdt + v);
     FUS_ST(un, v * adt + u);
-    FUS_ST(vn, kv * adt + v);
+    vnext = kv * adt + v;
+    FUS_ST(vn, vnext);
   }
   else if (STAGE == 3)
   {
     FUS_ST(u0, FUS_LD(vn) * bdt + FUS_LD(u_));
-    FUS_ST(v0, kv * bdt + FUS_LD(v_));
+    vnext = kv * bdt + FUS_LD(v_);
+    FUS_ST(v0, vnext);
   }
   else
   {
@@ -787,11 +790,43 @@ __device__ __forceinline__ void stage_update_dof(int64_t s, T acc, const T* __re
     FUS_ST(u_, w * bdt + FUS_LD(u_));
     FUS_ST(v_, kv * bdt + FUS_LD(v_));
     FUS_ST(un, w * adt + FUS_LD(u0));
-    FUS_ST(vn, kv * adt + FUS_LD(v0));
+    vnext = kv * adt + FUS_LD(v0);
+    FUS_ST(vn, vnext);
   }
 #undef FUS_LD
 #undef FUS_ST
+  return vnext;
 }
+
+// Boundary term of a shared boundary dof for the NEXT stage, produced where that dof's stage update
+// has just finished (its new stage velocity is in a register): the dof's last CSR entry is a pseudo
+// pair (index >= npairs) exactly when it is a boundary dof, and slot k = pair - npairs holds
+//   g(t_next) src[k] - abs[k] v_next (+ dg(t_next) src2[k])        (Linear.hpp:205; forms.py:38-39)
+// -- what k_boundary_partial computes in a launch of its own.  enabled = 0: leave the slots alone.
+template <typename T>
+struct BndNext
+{
+  int enabled;
+  int32_t npairs;
+  const T *srcw, *absw, *src2w;
+  T gnext, dgnext;
+  T* partial;
+};
+
+template <typename T>
+__device__ __forceinline__ void boundary_next(const BndNext<T>& B, int32_t last_pair, T vnext)
+{
+  if (B.enabled && last_pair >= B.npairs)
+  {
+    const int32_t k = last_pair - B.npairs;
+    T v = B.gnext * B.srcw[k] - B.absw[k] * vnext;
+    if (B.src2w)
+      v += B.dgnext * B.src2w[k];
+    B.partial[last_pair] = v;
+  }
+}
+
+
 
 // Shared dofs of one rank: fixed-order sum of the partials fused with the RK4 stage update of
 // stage_update_dof; vectors are passed offset to the shared range.
@@ -801,15 +836,20 @@ k_shared_stage(int64_t n, const int32_t* __restrict__ sh_ptr, const int32_t* __r
                const T* __restrict__ partial, const T* __restrict__ minv, T* __restrict__ vn,
                T* __restrict__ un, T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ u_,
                T* __restrict__ v_, T adt, T bdt, const T* __restrict__ m0,
-               const T* __restrict__ mn1)
+               const T* __restrict__ mn1, const BndNext<T> B)
 {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n)
     return;
   T acc = T(0);
+  int32_t pair = 0;
   for (int32_t k = sh_ptr[s]; k < sh_ptr[s + 1]; ++k)
-    acc += partial[sh_pairs[k]];
-  stage_update_dof<T, STAGE>(s, acc, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0, mn1);
+  {
+    pair = sh_pairs[k];
+    acc += partial[pair];
+  }
+  const T vnext = stage_update_dof<T, STAGE>(s, acc, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0, mn1);
+  boundary_next<T>(B, pair, vnext);
 }
 
 // Interface dofs (held by other ranks too), first half of the exchange: this rank's total of each
@@ -836,7 +876,7 @@ __global__ void k_if_reduce_pack(int64_t n, const int32_t* __restrict__ pack_idx
 
 // Second half: every sharer adds the ranks' totals of an interface dof in ascending rank order
 // (identical bits everywhere, see k_unpack_ordered) and finishes the RK stage for it.  Vectors are
-// passed whole (internal numbering).
+// passed whole (internal numbering); sh0 = internal index of shared slot 0 (for the dof's CSR row).
 template <typename T, int STAGE>
 __global__ void __launch_bounds__(256)
 k_if_unpack_stage(int64_t nu, const int32_t* __restrict__ uidx, const int32_t* __restrict__ uptr,
@@ -844,7 +884,8 @@ k_if_unpack_stage(int64_t nu, const int32_t* __restrict__ uidx, const int32_t* _
                   const T* __restrict__ b, const T* __restrict__ minv, T* __restrict__ vn,
                   T* __restrict__ un, T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ u_,
                   T* __restrict__ v_, T adt, T bdt, const T* __restrict__ m0,
-                  const T* __restrict__ mn1)
+                  const T* __restrict__ mn1, int64_t sh0, const int32_t* __restrict__ sh_ptr,
+                  const int32_t* __restrict__ sh_pairs, const BndNext<T> B)
 {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nu)
@@ -857,7 +898,9 @@ k_if_unpack_stage(int64_t nu, const int32_t* __restrict__ uidx, const int32_t* _
     const int32_t sidx = usrc[k];
     acc += (sidx < 0) ? own : recvbuf[sidx];
   }
-  stage_update_dof<T, STAGE>(u, acc, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0, mn1);
+  const T vnext = stage_update_dof<T, STAGE>(u, acc, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0, mn1);
+  if (B.enabled)
+    boundary_next<T>(B, sh_pairs[sh_ptr[u - sh0 + 1] - 1], vnext);
 }
 
 // Boundary term of shared boundary dofs, written as one more partial (summed last):

@@ -1514,9 +1514,9 @@ int fus_finalize(fus_ctx* c)
   for (auto& kv : c->profs)
     for (auto& ev : kv.second.ev)
       (void)hipEventDestroy(ev.first), (void)hipEventDestroy(ev.second);
+  (void)hipStreamSynchronize(c->comm_stream);
   if (c->comm)
     g_rccl.CommDestroy(c->comm);
-  (void)hipStreamSynchronize(c->comm_stream);
   (void)hipEventDestroy(c->ev_packed), (void)hipEventDestroy(c->ev_recv);
   (void)hipStreamDestroy(c->comm_stream);
   (void)hipStreamDestroy(c->stream);

@@ -2192,3 +2192,14 @@ int fus_profile_get(fus_ctx* c, const char* name, double* total_ms, int64_t* cou
 
 } // extern "C"
 #endif  // !FUS_TU_DEGREE
+
+#if defined(FUS_TRACE) && defined(FUS_TU_DEGREE)
+// experiment builds: phase timestamps of the last k_block_op launch of this degree's unit
+extern "C" int fus_debug_trace(unsigned long long* out, long long nblocks)
+{
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(fus::g_fus_trace), (size_t)nblocks * 8 * sizeof(unsigned long long))
+                 == hipSuccess
+             ? 0
+             : -2;
+}
+#endif

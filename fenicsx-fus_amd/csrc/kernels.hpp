@@ -115,6 +115,20 @@ enum
   OP_MASS = 1
 };
 
+// Phase timestamps of k_block_op (experiment builds only, -DFUS_TRACE): per block 8 slots of the
+// 100 MHz wall clock -- 0 start, 1 prologue done, 2 trips done, 3 epilogue done; 4 = CU id.
+#ifdef FUS_TRACE
+__device__ unsigned long long g_fus_trace[65536 * 8];
+#define FUS_STAMP(blk, k)                                                                          \
+  do                                                                                               \
+  {                                                                                                \
+    if (threadIdx.x == 0 && (blk) < 65536)                                                         \
+      g_fus_trace[(size_t)(blk) * 8 + (k)] = wall_clock64();                                       \
+  } while (0)
+#else
+#define FUS_STAMP(blk, k)
+#endif
+
 // Geometry source of the block operator
 //   GEOM_STREAM: per-point factors G / detJw streamed from HBM (any trilinear mesh; the reference's
 //                data path, precompute.hpp:101-213)
@@ -467,6 +481,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     return (int)rt_l[r * slots + myslot];
   };
 
+  FUS_STAMP(blk, 0);
   // first trip's geometry is requested before the block's dof values are staged
   ElemIn<T, N, OP, GEOM, TD> inA, inB;
   {
@@ -476,97 +491,132 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     elem_fetch<T, N, OP, GEOM, TD>(inA, e0, geo, elem_off, p);
   }
 
-  // ---- prologue: stage the block's dof values in LDS, clear the accumulator; all loads of a
-  // pass are issued before the first LDS store so one HBM round trip covers the whole block ----
+  // ---- prologue: stage the block's dof values, local dofmaps and coefficients in LDS, clear the
+  // accumulator.  Measured (phase timestamps, tools/gpu_trace.py) the prologue was the longest phase
+  // of a block when each of its copy loops waited for its own memory round trip, so every load that
+  // does not depend on another is issued first (one round trip), the gather of the shared dofs
+  // (it needs their indices) second, and only then the LDS stores.  Blocks larger than the first
+  // batches finish in plain loops. ----
   {
     typedef T V2 __attribute__((ext_vector_type(2)));
-    constexpr int UN = 8;
+    typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+    constexpr int UI = 4, US = 5, UL = 4;  // per thread: interior 16-B vectors, shared dofs, dofmap 16-B vectors
     const V2* xg = reinterpret_cast<const V2*>(x + int_off);  // int_off is a multiple of 16
     const V2* xg2 = reinterpret_cast<const V2*>((NF == 2 ? S.x2 : x) + int_off);
     const int nvec = sh.nint >> 1;
-    for (int base = tid; base < nvec; base += nthr * UN)
-    {
-      V2 v[UN], v2[UN];
-#pragma unroll
-      for (int u = 0; u < UN; ++u)
-        if (base + u * nthr < nvec)
-        {
-          v[u] = xg[base + u * nthr];
-          if (NF == 2)
-            v2[u] = xg2[base + u * nthr];
-        }
-#pragma unroll
-      for (int u = 0; u < UN; ++u)
-        if (base + u * nthr < nvec)
-        {
-          reinterpret_cast<V2*>(x_l)[base + u * nthr] = v[u];
-          if (NF == 2)
-            reinterpret_cast<V2*>(x2_l)[base + u * nthr] = v2[u];
-          reinterpret_cast<V2*>(y_l)[base + u * nthr] = V2(T(0));
-        }
-    }
-    if (tid == 0 && (sh.nint & 1))
-    {
-      x_l[sh.nint - 1] = x[int_off + sh.nint - 1];
-      if (NF == 2)
-        x2_l[sh.nint - 1] = S.x2[int_off + sh.nint - 1];
-      y_l[sh.nint - 1] = T(0);
-    }
     const int nsh = sh.nloc - sh.nint;
     const int32_t* gix = A.sh_gidx + sh_off;
-    for (int base = tid; base < nsh; base += nthr * UN)
-    {
-      int gi[UN];
-      T v[UN], v2[UN];
+    const int n16 = (sh.nelem * Nd * 2 + 15) >> 4;  // ldm_off is a multiple of 8 entries
+    const U4* lsrc = reinterpret_cast<const U4*>(A.ldm + sh.ldm_off);
+    const int ngc = (GEOM == GEOM_AFFINE) ? sh.nelem * 7 : 0;
+
+    // round trip 1
+    V2 xi[UI], xi2[UI];
+    int gi[US];
+    U4 lq[UL];
 #pragma unroll
-      for (int u = 0; u < UN; ++u)
-        gi[u] = (base + u * nthr < nsh) ? gix[base + u * nthr] : 0;
-#pragma unroll
-      for (int u = 0; u < UN; ++u)
+    for (int u = 0; u < UI; ++u)
+      if (tid + u * nthr < nvec)
       {
-        v[u] = x[gi[u]];
+        xi[u] = xg[tid + u * nthr];
         if (NF == 2)
-          v2[u] = S.x2[gi[u]];
+          xi2[u] = xg2[tid + u * nthr];
       }
 #pragma unroll
-      for (int u = 0; u < UN; ++u)
-        if (base + u * nthr < nsh)
-        {
-          x_l[sh.nint + base + u * nthr] = v[u];
-          if (NF == 2)
-            x2_l[sh.nint + base + u * nthr] = v2[u];
-          y_l[sh.nint + base + u * nthr] = T(0);
-        }
-    }
-    // this block's round table -> LDS, so the per-round element lookup is not a global load that
-    // would drain the geometry prefetch queue (vmcnt retires in order)
-    for (int k = tid; k < sh.nrounds * slots; k += nthr)
-      rt_l[k] = A.rounds[sh.rounds_off + k];
-    // local dofmaps, coefficients and the derivative table likewise (LDS reads retire on lgkmcnt)
+    for (int u = 0; u < US; ++u)
+      gi[u] = (tid + u * nthr < nsh) ? gix[tid + u * nthr] : 0;
+#pragma unroll
+    for (int u = 0; u < UL; ++u)
+      if (tid + u * nthr < n16)
+        lq[u] = lsrc[tid + u * nthr];
+    const T cfv = (tid < sh.nelem) ? coef[elem_off + tid] : T(0);
+    const T cf2v = (NF == 2 && tid < sh.nelem) ? S.coef2[elem_off + tid] : T(0);
+    const T gcv = (tid < ngc) ? geo[(int64_t)elem_off * 7 + tid] : T(0);
+    const T dgv = (tid < N2 + N) ? Dg[tid] : T(0);  // derivative table, then the 1-D weights
+    const T xtail = (tid == 0 && (sh.nint & 1)) ? x[int_off + sh.nint - 1] : T(0);
+    const T xtail2 = (NF == 2 && tid == 0 && (sh.nint & 1)) ? S.x2[int_off + sh.nint - 1] : T(0);
+    // round trip 2: the shared dofs' values
+    T xs[US], xs2[US];
+#pragma unroll
+    for (int u = 0; u < US; ++u)
     {
-      typedef uint32_t U4 __attribute__((ext_vector_type(4)));
-      const int n16 = (sh.nelem * Nd * 2 + 15) >> 4;  // ldm_off is a multiple of 8 entries
-      const U4* src = reinterpret_cast<const U4*>(A.ldm + sh.ldm_off);
-      for (int k = tid; k < n16; k += nthr)
-        reinterpret_cast<U4*>(ldm_l)[k] = src[k];
+      xs[u] = x[gi[u]];
+      if (NF == 2)
+        xs2[u] = S.x2[gi[u]];
     }
-    for (int k = tid; k < sh.nelem; k += nthr)
+    // LDS stores
+#pragma unroll
+    for (int u = 0; u < UI; ++u)
+      if (tid + u * nthr < nvec)
+      {
+        reinterpret_cast<V2*>(x_l)[tid + u * nthr] = xi[u];
+        if (NF == 2)
+          reinterpret_cast<V2*>(x2_l)[tid + u * nthr] = xi2[u];
+        reinterpret_cast<V2*>(y_l)[tid + u * nthr] = V2(T(0));
+      }
+#pragma unroll
+    for (int u = 0; u < UL; ++u)
+      if (tid + u * nthr < n16)
+        reinterpret_cast<U4*>(ldm_l)[tid + u * nthr] = lq[u];
+    if (tid < sh.nelem)
+    {
+      cf_l[tid] = cfv;
+      if (NF == 2)
+        cf2_l[tid] = cf2v;
+    }
+    if (tid < ngc)
+      gc_l[tid] = gcv;
+    if (tid < N2)
+      D_l[tid] = dgv;
+    if (GEOM == GEOM_AFFINE && tid >= N2 && tid < N2 + N)
+      w_l[tid - N2] = dgv;
+    if (tid == 0 && (sh.nint & 1))
+    {
+      x_l[sh.nint - 1] = xtail;
+      if (NF == 2)
+        x2_l[sh.nint - 1] = xtail2;
+      y_l[sh.nint - 1] = T(0);
+    }
+#pragma unroll
+    for (int u = 0; u < US; ++u)
+      if (tid + u * nthr < nsh)
+      {
+        x_l[sh.nint + tid + u * nthr] = xs[u];
+        if (NF == 2)
+          x2_l[sh.nint + tid + u * nthr] = xs2[u];
+        y_l[sh.nint + tid + u * nthr] = T(0);
+      }
+    // leftovers of large blocks
+    for (int i = tid + UI * nthr; i < nvec; i += nthr)
+    {
+      reinterpret_cast<V2*>(x_l)[i] = xg[i];
+      if (NF == 2)
+        reinterpret_cast<V2*>(x2_l)[i] = xg2[i];
+      reinterpret_cast<V2*>(y_l)[i] = V2(T(0));
+    }
+    for (int i = tid + US * nthr; i < nsh; i += nthr)
+    {
+      const int g = gix[i];
+      x_l[sh.nint + i] = x[g];
+      if (NF == 2)
+        x2_l[sh.nint + i] = S.x2[g];
+      y_l[sh.nint + i] = T(0);
+    }
+    for (int k = tid + UL * nthr; k < n16; k += nthr)
+      reinterpret_cast<U4*>(ldm_l)[k] = lsrc[k];
+    for (int k = tid + nthr; k < sh.nelem; k += nthr)
     {
       cf_l[k] = coef[elem_off + k];
       if (NF == 2)
         cf2_l[k] = S.coef2[elem_off + k];
     }
-    if (tid < N2)
-      D_l[tid] = Dg[tid];
-    if (GEOM == GEOM_AFFINE)
-    {
-      // per-cell geometry (geo = [elem][7]: Gxx,Gxy,Gxz,Gyy,Gyz,Gzz,|detJ|) and the 1-D weights
-      // (Dg carries them after the N*N table)
-      for (int k = tid; k < sh.nelem * 7; k += nthr)
-        gc_l[k] = geo[(int64_t)elem_off * 7 + k];
-      if (tid < N)
-        w_l[tid] = Dg[N2 + tid];
-    }
+    for (int k = tid + nthr; k < ngc; k += nthr)
+      gc_l[k] = geo[(int64_t)elem_off * 7 + k];
+    // the round table (deterministic mode only) -> LDS, so the per-round element lookup is not a
+    // global load that would drain the geometry prefetch queue (vmcnt retires in order)
+    if (!ATOMIC)
+      for (int k = tid; k < sh.nrounds * slots; k += nthr)
+        rt_l[k] = A.rounds[sh.rounds_off + k];
   }
 
   T* sA = scratch + (size_t)(wave * EPW + (active ? s : 0)) * Nd;
@@ -574,6 +624,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
 
   // lane-dependent rows/columns of the derivative table (tiny, cache resident)
   __syncthreads();
+  FUS_STAMP(blk, 1);
   T Drb[N], Drc[N], Dcb[N], Dcc[N];
 #pragma unroll
   for (int j = 0; j < N; ++j)
@@ -616,6 +667,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   }
 #undef FUS_ELEM_COMPUTE
   __syncthreads();
+  FUS_STAMP(blk, 2);
 
   // ---- epilogue: each dof written once ----
   typedef T V2 __attribute__((ext_vector_type(2)));
@@ -723,6 +775,12 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   }
   for (int l = sh.nint + tid; l < sh.nloc; l += nthr)
     partial[sh_off + (l - sh.nint)] = y_l[l];
+#ifdef FUS_TRACE
+  __syncthreads();
+  FUS_STAMP(blk, 3);
+  if (threadIdx.x == 0 && blk < 65536)
+    g_fus_trace[(size_t)blk * 8 + 4] = __smid();
+#endif
 }
 
 // bsh[s] = sum over the (block, slot) pairs of shared dof s, ascending block order (a trailing

@@ -232,10 +232,10 @@ def main():
         achieved = alg_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         value = (ndl if args.halo_loopback else ndofs_global) * args.steps / elapsed
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
-        # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01f_pmc_traffic.json, tools/gpu_profile.sh); only quoted
+        # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01g_pmc_traffic.json, tools/gpu_profile.sh); only quoted
         # for the configuration those passes were taken on
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01f_pmc_traffic.json")
+        pmc = os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")
         if (os.path.exists(pmc) and n == 64 and P == 4 and args.block_elems is None and args.waves is None
                 and not args.deterministic and not affine):
             traffic = json.load(open(pmc))["k_block_op_fused"]["hbm_bytes_per_launch"]
@@ -262,7 +262,7 @@ def main():
                        "lds_bytes_per_block": info["lds_bytes"], "dt": dt},
             "roofline": {"bound": "hbm", "kernel": f"k_block_op<{'double' if args.dtype == 'f64' else 'float'},{P},stiffness,+fused RK4 stage>", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         "traffic_source": "profiles/r01f_pmc_traffic.json (separate rocprofv3 --pmc passes)",
+                         "traffic_source": "profiles/r01g_pmc_traffic.json (separate rocprofv3 --pmc passes)",
                          "algorithmic_bytes_per_launch": alg_launch, "interior_dofs": n_int, "avg_launch_ms": avg_ms,
                          "launches": k_cnt},
             "step_roofline": {"algorithmic_bytes_per_dof_update": b_general,

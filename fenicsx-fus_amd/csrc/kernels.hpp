@@ -655,12 +655,18 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     const bool has1 = r + 1 < ntrips;
     elem_fetch<T, N, OP, GEOM, TD>(inB, elem_of(r + 1), geo, elem_off, p);
     FUS_ELEM_COMPUTE(inA);
+    if (r == 0)
+      FUS_STAMP(blk, 5);
+    if (r == 2)
+      FUS_STAMP(blk, 7);
     if (!ATOMIC && A.waves > 1)
       __syncthreads();
     elem_fetch<T, N, OP, GEOM, TD>(inA, elem_of(r + 2), geo, elem_off, p);
     if (has1)
     {
       FUS_ELEM_COMPUTE(inB);
+      if (r == 0)
+        FUS_STAMP(blk, 6);
       if (!ATOMIC && A.waves > 1)
         __syncthreads();
     }

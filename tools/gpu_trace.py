@@ -34,6 +34,11 @@ pro, trips, epi = t[:, 1] - t[:, 0], t[:, 2] - t[:, 1], t[:, 3] - t[:, 2]
 print(f"geometry={geom} blocks={nb} kernel span {t[:, 3].max() - t0:.1f} us")
 for name, d in (("prologue", pro), ("trips", trips), ("epilogue", epi), ("block total", t[:, 3] - t[:, 0])):
     print(f"  {name:12s} mean {d.mean():6.2f}  median {np.median(d):6.2f}  p10 {np.percentile(d, 10):6.2f}  p90 {np.percentile(d, 90):6.2f} us")
+if buf[:, 5].any():   # wave 0's first three element trips (stamps 5, 6, 7) and the rest up to the barrier
+    tt = buf[:, 5:8].astype(np.float64) / 100.0
+    for name, d in (("trip 0", tt[:, 0] - t[:, 1]), ("trip 1", tt[:, 1] - tt[:, 0]), ("trip 2", tt[:, 2] - tt[:, 1]),
+                    ("trip 3 + barrier", t[:, 2] - tt[:, 2])):
+        print(f"  {name:16s} mean {d.mean():6.2f}  median {np.median(d):6.2f} us")
 # start-time histogram: how staggered are the blocks
 order = np.argsort(t[:, 0])
 print("  first 8 block start offsets (us):", np.round(t[order[:8], 0] - t0, 2))

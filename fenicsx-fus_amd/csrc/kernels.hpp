@@ -586,24 +586,65 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
           x2_l[sh.nint + tid + u * nthr] = xs2[u];
         y_l[sh.nint + tid + u * nthr] = T(0);
       }
-    // leftovers of large blocks
-    for (int i = tid + UI * nthr; i < nvec; i += nthr)
+    // leftovers of large blocks (higher degrees), again with the loads of a batch ahead of its stores
+    constexpr int UB = 8;
+    for (int base = tid + UI * nthr; base < nvec; base += nthr * UB)
     {
-      reinterpret_cast<V2*>(x_l)[i] = xg[i];
-      if (NF == 2)
-        reinterpret_cast<V2*>(x2_l)[i] = xg2[i];
-      reinterpret_cast<V2*>(y_l)[i] = V2(T(0));
+      V2 v[UB], v2[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (base + u * nthr < nvec)
+        {
+          v[u] = xg[base + u * nthr];
+          if (NF == 2)
+            v2[u] = xg2[base + u * nthr];
+        }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (base + u * nthr < nvec)
+        {
+          reinterpret_cast<V2*>(x_l)[base + u * nthr] = v[u];
+          if (NF == 2)
+            reinterpret_cast<V2*>(x2_l)[base + u * nthr] = v2[u];
+          reinterpret_cast<V2*>(y_l)[base + u * nthr] = V2(T(0));
+        }
     }
-    for (int i = tid + US * nthr; i < nsh; i += nthr)
+    for (int base = tid + US * nthr; base < nsh; base += nthr * UB)
     {
-      const int g = gix[i];
-      x_l[sh.nint + i] = x[g];
-      if (NF == 2)
-        x2_l[sh.nint + i] = S.x2[g];
-      y_l[sh.nint + i] = T(0);
+      int g[UB];
+      T v[UB], v2[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        g[u] = (base + u * nthr < nsh) ? gix[base + u * nthr] : 0;
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+      {
+        v[u] = x[g[u]];
+        if (NF == 2)
+          v2[u] = S.x2[g[u]];
+      }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (base + u * nthr < nsh)
+        {
+          x_l[sh.nint + base + u * nthr] = v[u];
+          if (NF == 2)
+            x2_l[sh.nint + base + u * nthr] = v2[u];
+          y_l[sh.nint + base + u * nthr] = T(0);
+        }
     }
-    for (int k = tid + UL * nthr; k < n16; k += nthr)
-      reinterpret_cast<U4*>(ldm_l)[k] = lsrc[k];
+    for (int base = tid + UL * nthr; base < n16; base += nthr * UB)
+    {
+      U4 q[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (base + u * nthr < n16)
+          q[u] = lsrc[base + u * nthr];
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (base + u * nthr < n16)
+          reinterpret_cast<U4*>(ldm_l)[base + u * nthr] = q[u];
+    }
     for (int k = tid + nthr; k < sh.nelem; k += nthr)
     {
       cf_l[k] = coef[elem_off + k];

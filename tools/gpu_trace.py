@@ -12,7 +12,8 @@ import fenicsxfus_amd as fa  # noqa: E402
 from fenicsxfus_amd import _abi  # noqa: E402
 
 geom = sys.argv[1] if len(sys.argv) > 1 else "stream"
-n, P = 64, 4
+P = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+n = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 L = 0.12
 mesh = fa.BoxMesh([0, 0, 0], [L, L, L], (n, n, n))
 V = fa.FunctionSpace(mesh, P)

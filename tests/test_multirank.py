@@ -258,3 +258,84 @@ def test_rccl_binding_selftest():
     c = fa.Context(0)
     c.comm_selftest(1 << 18)
     c.close()
+
+
+@pytest.mark.gpu
+def test_general_partition_four_quadrants_gpu(orc):
+    """A partition DOLFINx could produce rather than slabs: the box cut into 2 x 2 quadrants in x-y,
+    every rank an unstructured local mesh with its own (geometric) DOF numbering, neighbour lists
+    built from global DOF identity and ordered by it.  Interface faces are not contiguous index
+    ranges, and the DOFs on the central line are held by all four ranks -- each adds the four partial
+    sums in ascending rank order.  In-process transport on one GPU against the single-rank oracle."""
+    from fenicsxfus_amd.unstructured import HexFunctionSpace, HexMesh
+    n, hi, Pq, nsteps = (4, 4, 3), [0.016, 0.016, 0.012], 3, 5
+    pr = Problem(orc, n, Pq, hi=hi, perturb=0.1)
+    nc = pr.mesh.num_cells
+    cen = pr.mesh.cell_centroids()
+    c = np.where(cen[:, 2] > 0.5 * hi[2], 2800.0, 1500.0)
+    rho = np.where(cen[:, 2] > 0.5 * hi[2], 1850.0, 1000.0)
+    gtags = fa.tag_box_boundary(pr.mesh)
+    m, src, absb, coeff = pr.linear_model_vectors(c, rho, gtags)
+    dt = 0.4 * (hi[0] / n[0]) / (2800.0 * Pq**2)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, F0, P0, S0, 0.0, nsteps * dt * (1 + 1e-12), dt, u, v)
+    assert np.abs(u).max() > 0
+    from scipy.spatial import cKDTree
+    # true (mapped) positions of the global dofs: the same trilinear map the local spaces use
+    Xg = np.zeros((pr.ndofs, 3))
+    Xg[pr.dm] = HexFunctionSpace(HexMesh(pr.mesh.geometry.x, pr.mesh.geometry.dofmap), Pq)._node_x
+    tree = cKDTree(Xg)
+
+    def global_ids(X):
+        d, i = tree.query(X)
+        assert d.max() < 1e-9 * max(hi)
+        return i
+    quad = (cen[:, 0] > 0.5 * hi[0]).astype(int) + 2 * (cen[:, 1] > 0.5 * hi[1]).astype(int)
+    size = 4
+    ctxs = [fa.Context(0, block_elems=4) for _ in range(size)]
+    fa.Context.init_local_group(ctxs)
+    models, gids = [], []
+    for r in range(size):
+        cells = np.nonzero(quad == r)[0]
+        used, inv = np.unique(pr.mesh.geometry.dofmap[cells], return_inverse=True)
+        lmesh = HexMesh(pr.mesh.geometry.x[used], inv.reshape(len(cells), 8))
+        V = HexFunctionSpace(lmesh, Pq)
+        gids.append(global_ids(V.tabulate_dof_coordinates()))
+        # global-boundary facets of this rank's cells, as (local cell, local facet, tag)
+        loc_of = {g: i for i, g in enumerate(cells)}
+        sel = np.isin(gtags.cells, cells)
+        tags = fa.FacetTags(np.array([loc_of[g] for g in gtags.cells[sel]], np.int32), gtags.local_facets[sel],
+                            gtags.values[sel])
+        models.append((lmesh, V, tags, c[cells], rho[cells]))
+    for r in range(size):       # neighbour lists: shared global dofs, ordered by global id on both sides
+        lmesh, V, tags, cr, rr = models[r]
+        V.neighbours = []
+        mine = {g: i for i, g in enumerate(gids[r])}
+        for q in range(size):
+            if q == r:
+                continue
+            shared = np.intersect1d(gids[r], gids[q])
+            if len(shared):
+                V.neighbours.append((q, np.array([mine[g] for g in shared], dtype=np.int32)))
+        assert len(V.neighbours) == 3                     # every quadrant touches the central line
+    four = set(gids[0]) & set(gids[1]) & set(gids[2]) & set(gids[3])
+    assert len(four) == n[2] * Pq + 1                     # dofs held by all four ranks
+    mods = [fa.LinearSpectralExplicit(lm, tg, Pq, cr, rr, F0, P0, S0, 4, dt, V=V, ctx=ctxs[r])
+            for r, (lm, V, tg, cr, rr) in enumerate(models)]
+    fa.group_finish_setup(mods)
+    for mdl in mods:
+        mdl.init()
+    fa.group_rk4_steps(mods, 0.0, dt, nsteps)
+    sols = []
+    for r, mdl in enumerate(mods):
+        assert np.abs(mdl.mass_vector() - m[gids[r]]).max() < 1e-14 * np.abs(m).max()
+        ur = mdl.u_sol().x.array
+        sols.append(dict(zip(gids[r].tolist(), ur.tolist())))
+        assert np.abs(ur - u[gids[r]]).max() < 1e-10 * np.abs(u).max()
+        assert np.abs(mdl.v_n.x.array - v[gids[r]]).max() < 1e-10 * np.abs(v).max()
+    for g in four:                                        # identical bits on all four sharers
+        assert len({sols[r][g] for r in range(size)}) == 1
+    for mdl in mods:
+        mdl.close()
+    for cx in ctxs:
+        cx.close()

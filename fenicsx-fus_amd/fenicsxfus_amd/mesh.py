@@ -66,6 +66,7 @@ class BoxMesh:
         self.hi = np.asarray(hi, dtype=np.float64)
         self.rank, self.size = rank, size
         self.dtype = np.dtype(dtype)
+        self.perturbed = bool(perturb)
         nx = self.n[0]
         assert size <= nx, "more ranks than element layers"
         # contiguous slabs of element layers along x
@@ -247,6 +248,8 @@ class FunctionSpace:
     def tabulate_dof_coordinates(self):
         m, P = self.mesh, self.P
         N = P + 1
+        if getattr(m, "perturbed", False) or getattr(m, "order", 1) == 2:
+            return self._mapped_dof_coordinates()
         pts, _ = tables.gll(N)
         axes = []
         for d in range(m.tdim):
@@ -260,6 +263,30 @@ class FunctionSpace:
         for d in range(m.tdim):
             x[:, d] = grid[d].ravel()
         return x
+
+
+    def _mapped_dof_coordinates(self):
+        """Physical positions of the dofs through the cells' geometry map (perturbed / curved meshes):
+        tensor Lagrange basis of the geometry order at the element's GLL nodes."""
+        m, t = self.mesh, self.mesh.tdim
+        g = getattr(m, "order", 1)
+        x = np.asarray(m.geometry.x, dtype=np.float64)
+        cd = x[m.geometry.dofmap]                                      # [nc, (g+1)^t, 3]
+        grids = np.meshgrid(*([np.asarray(self.nodes1d)] * t), indexing="ij")
+        X = np.stack([gr.ravel() for gr in grids], axis=1)             # element node i -> reference point
+
+        def basis1d(xv):
+            if g == 1:
+                return np.stack([1.0 - xv, xv], axis=1)
+            return np.stack([(2 * xv - 1) * (xv - 1), 4 * xv * (1 - xv), xv * (2 * xv - 1)], axis=1)
+
+        phi = np.ones((X.shape[0], (g + 1) ** t))
+        for n in range((g + 1) ** t):
+            for d in range(t):
+                phi[:, n] *= basis1d(X[:, d])[:, (n // (g + 1) ** d) % (g + 1)]
+        out = np.zeros((self.num_dofs, 3))
+        out[self.tensor_dofmap] = np.einsum("qn,cnk->cqk", phi, cd)
+        return out
 
 
 class _Vec:

@@ -218,7 +218,7 @@ def test_second_order_geometry(orc):
     assert abs(z @ y - x @ c.K(z)) < 1e-11 * abs(z @ y)
     assert np.abs(y - c.K(x, dense=True)).max() < 1e-12 * np.abs(y).max()
     assert abs(c.M(np.ones(c.ndofs)).sum() - np.prod(L)) < 1e-13 * np.prod(L)
-    Xp = _bend(c.V.tabulate_dof_coordinates())                           # physical dof coordinates
+    Xp = c.V.tabulate_dof_coordinates()           # physical dof coordinates (through the triquadratic map)
     u = Xp[:, 0].copy()                                                  # grad u = e_x everywhere
     assert abs(u @ c.K(u) - np.prod(L)) < 1e-12 * np.prod(L)
     # boundary weights: area of the bent x = 0 face, tangents (0.6y, 1, 0) and (-0.4z, 0.5z, 1)

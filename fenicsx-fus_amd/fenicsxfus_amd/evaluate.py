@@ -1,4 +1,5 @@
-"""Point evaluation of a degree-P GLL field on first-order hexahedra (post-processing, host side).
+"""Point evaluation of a degree-P GLL field on first-order hexahedra or quadrilaterals
+(post-processing, host side).
 
 The reference samples its solutions on lines/planes with DOLFINx's ``Function.eval`` after locating
 the cells (``compute_eval_params``, python/src/fenicsxfus/utils.py:10-47;
@@ -13,37 +14,42 @@ from scipy.spatial import cKDTree
 
 
 def _shape(X):
-    """Trilinear shape functions and their reference gradients at X [n,3] -> phi [n,8], dphi [n,8,3]."""
-    n = X.shape[0]
-    phi = np.ones((n, 8))
-    dphi = np.ones((n, 8, 3))
-    for v in range(8):
-        for d in range(3):
+    """Multilinear shape functions and their reference gradients at X [n,t] (t = 2 | 3) ->
+    phi [n,2^t], dphi [n,2^t,t]."""
+    n, t = X.shape
+    nv = 1 << t
+    phi = np.ones((n, nv))
+    dphi = np.ones((n, nv, t))
+    for v in range(nv):
+        for d in range(t):
             bit = (v >> d) & 1
             f = X[:, d] if bit else 1.0 - X[:, d]
             phi[:, v] *= f
-            for e in range(3):
+            for e in range(t):
                 dphi[:, v, e] *= (1.0 if bit else -1.0) if e == d else f
     return phi, dphi
 
 
 def locate(mesh, points, ncand: int = 32, tol: float = 1e-10):
     """For each point: (cell, reference coordinates) of a cell containing it, cell = -1 if none."""
-    pts = np.atleast_2d(np.asarray(points, dtype=np.float64))
-    x = np.asarray(mesh.geometry.x, dtype=np.float64)
+    t = mesh.topology.dim
     cells = np.asarray(mesh.geometry.dofmap)
+    if cells.shape[1] != (1 << t):
+        raise NotImplementedError("point location needs first-order cells")
+    pts = np.atleast_2d(np.asarray(points, dtype=np.float64))[:, :t]
+    x = np.asarray(mesh.geometry.x, dtype=np.float64)[:, :t]
     cen = x[cells].mean(axis=1)
     _, cand = cKDTree(cen).query(pts, k=min(ncand, len(cen)))
     cand = cand.reshape(len(pts), -1)
     out_cell = np.full(len(pts), -1, dtype=np.int64)
-    out_X = np.zeros((len(pts), 3))
+    out_X = np.zeros((len(pts), t))
     todo = np.arange(len(pts))
     for k in range(cand.shape[1]):
         if len(todo) == 0:
             break
         c = cand[todo, k]
-        cd = x[cells[c]]                                   # [m, 8, 3]
-        X = np.full((len(todo), 3), 0.5)
+        cd = x[cells[c]]                                   # [m, 2^t, t]
+        X = np.full((len(todo), t), 0.5)
         for _ in range(25):                                # Newton on x(X) = p
             phi, dphi = _shape(X)
             r = np.einsum("mv,mvi->mi", phi, cd) - pts[todo]
@@ -81,7 +87,12 @@ def evaluate(V, u, points):
 
     out = np.full(len(cell), np.nan)
     ok = cell >= 0
-    b0, b1, b2 = basis(X[ok, 0]), basis(X[ok, 1]), basis(X[ok, 2])
-    dofs = np.asarray(V.tensor_dofmap)[cell[ok]].reshape(-1, N, N, N)
-    out[ok] = np.einsum("mi,mj,mk,mijk->m", b0, b1, b2, ua[dofs])
+    if X.shape[1] == 3:
+        b0, b1, b2 = basis(X[ok, 0]), basis(X[ok, 1]), basis(X[ok, 2])
+        dofs = np.asarray(V.tensor_dofmap)[cell[ok]].reshape(-1, N, N, N)
+        out[ok] = np.einsum("mi,mj,mk,mijk->m", b0, b1, b2, ua[dofs])
+    else:
+        b0, b1 = basis(X[ok, 0]), basis(X[ok, 1])
+        dofs = np.asarray(V.tensor_dofmap)[cell[ok]].reshape(-1, N, N)
+        out[ok] = np.einsum("mi,mj,mij->m", b0, b1, ua[dofs])
     return out

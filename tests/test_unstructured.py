@@ -347,3 +347,25 @@ def test_second_order_quads_gpu(orc, curved):
     assert np.abs(uo).max() > 0 and rel(un.x.array, uo) < 1e-10 and rel(vn.x.array, vo) < 1e-10
     model.close()
     ctx.close()
+
+
+def test_point_evaluation_quadrilaterals(ref_mesh2d):
+    """evaluate() / locate() in 2-D: exact on an affine rectangle for a field of the space's degree,
+    spectrally accurate on the reference's Gmsh quadrilateral mesh."""
+    from fenicsxfus_amd.evaluate import evaluate, locate
+    box = fa.BoxMesh([0, 0], [1.0, 0.8], (4, 3))
+    Vb = fa.FunctionSpace(box, 4)
+    Xd = Vb.tabulate_dof_coordinates()
+    f = lambda X: X[:, 0] ** 4 - 2 * X[:, 1] ** 3 * X[:, 0] + X[:, 0] * X[:, 1] + 1.0  # noqa: E731
+    rng = np.random.default_rng(0)
+    pts = rng.uniform([0, 0], [1.0, 0.8], size=(200, 2))
+    assert np.abs(evaluate(Vb, f(Xd), pts) - f(pts)).max() < 1e-13
+    assert np.isnan(evaluate(Vb, f(Xd), np.array([[1.5, 0.1]]))).all()
+    qm, _ = ref_mesh2d
+    V = HexFunctionSpace(qm, 5)
+    X = V.tabulate_dof_coordinates()
+    u = np.sin(X[:, 0]) * np.cos(np.pi * X[:, 1])
+    pts = rng.uniform(0.02, 0.98, size=(300, 2))
+    cell, _ = locate(qm, pts)
+    assert (cell >= 0).all()
+    assert np.abs(evaluate(V, u, pts) - np.sin(pts[:, 0]) * np.cos(np.pi * pts[:, 1])).max() < 1e-6

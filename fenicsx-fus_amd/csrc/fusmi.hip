@@ -154,6 +154,7 @@ struct fus_ctx
   // and synchronisation cost (the received planes are its own: results are NOT the physical ones)
   bool loopback = false;
   bool overlap_blocks = false;  // launch interface blocks first, overlap the exchange with the rest
+  bool external_transport = false;  // the caller exchanges the packed interface values (e.g. GPU-aware MPI)
   // Lossy / Westervelt boundary forms: 0 = the C++ benchmarks (BM7-SC1/forms.py:37-42: absorbing and
   // delta-mass terms on every boundary facet, source doubled, Lossy.hpp:216-220); 1 = the Python
   // package (python/src/fenicsxfus/_lossy.py:107-128, :186-189: those terms on tag 2 only, source
@@ -1558,6 +1559,8 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
     c->loopback = value != 0;
   else if (!strcmp(key, "overlap_blocks"))
     c->overlap_blocks = value != 0;
+  else if (!strcmp(key, "external_transport"))
+    c->external_transport = value != 0;
   else if (!strcmp(key, "forms"))
   {
     if (value != 0 && value != 1)
@@ -1590,8 +1593,17 @@ int fus_comm_init(fus_ctx* c, int rank, int nranks, const void* id128)
   if (!c || nranks < 1 || rank < 0 || rank >= nranks)
     return fail(FUS_ERR_ARG, "bad rank/nranks");
   c->rank = rank, c->nranks = nranks;
+  if (c->external_transport)
+  {
+    // the caller moves the packed interface values itself (fus_op_halo_buffers): no communicator, the
+    // stage / setup halves are driven through fus_model_stage_begin/_end, fus_model_setup_*
+    c->local_group = nranks > 1;
+    return FUS_OK;
+  }
   if (nranks == 1 && !id128)
     return FUS_OK;
+  if (!id128)
+    return fail(FUS_ERR_ARG, "fus_comm_init: RCCL id missing (or set option external_transport)");
   FUSCHK(rccl_load());
   ncclUniqueId id;
   memcpy(&id, id128, 128);
@@ -2011,6 +2023,96 @@ int fus_group_rk4_steps(fus_model** ms, int n, double t0, double dt, int64_t nst
   }
   for (int i = 0; i < n; ++i)
     HIPCHK(hipStreamSynchronize(ms[i]->ctx->stream));
+  return FUS_OK;
+}
+
+// ---- external transport: the stage / setup halves one by one, the exchange is the caller's ----------
+int fus_op_halo_layout(fus_op* op, int* nneigh, int32_t* ranks, int64_t* counts, int64_t* offsets)
+{
+  if (!op || !nneigh)
+    return fail(FUS_ERR_ARG, "null argument");
+  *nneigh = (int)op->neigh.size();
+  for (size_t k = 0; k < op->neigh.size(); ++k)
+  {
+    if (ranks)
+      ranks[k] = op->neigh[k].rank;
+    if (counts)
+      counts[k] = op->neigh[k].count;
+    if (offsets)
+      offsets[k] = op->neigh[k].off;
+  }
+  return FUS_OK;
+}
+
+int fus_op_halo_buffers(fus_op* op, void** send_dev, void** recv_dev, int64_t* nvalues)
+{
+  if (!op)
+    return fail(FUS_ERR_ARG, "null op");
+  if (send_dev)
+    *send_dev = op->d_sendbuf;
+  if (recv_dev)
+    *recv_dev = op->d_recvbuf;
+  if (nvalues)
+    *nvalues = op->n_halo;
+  return FUS_OK;
+}
+
+static int external_model(fus_model* m)
+{
+  if (!m)
+    return fail(FUS_ERR_ARG, "null model");
+  if (!m->ctx->external_transport)
+    return fail(FUS_ERR_STATE, "set option external_transport before fus_comm_init to drive the halves yourself");
+  HIPCHK(hipSetDevice(m->ctx->device));
+  return FUS_OK;
+}
+
+int fus_model_setup_count(fus_model* m) { return m ? (m->mn1 ? 2 : 1) : 0; }
+
+int fus_model_setup_pack(fus_model* m, int k)
+{
+  FUSCHK(external_model(m));
+  if (k < 0 || k >= fus_model_setup_count(m))
+    return fail(FUS_ERR_ARG, "setup vector index out of range");
+  FUSCHK(d_halo_pack(m->op, setup_halo_vector(m, k)));
+  HIPCHK(hipStreamSynchronize(m->ctx->stream));   // the send buffer is complete on return
+  return FUS_OK;
+}
+
+int fus_model_setup_unpack(fus_model* m, int k)
+{
+  FUSCHK(external_model(m));
+  if (k < 0 || k >= fus_model_setup_count(m))
+    return fail(FUS_ERR_ARG, "setup vector index out of range");
+  return d_halo_unpack(m->op, setup_halo_vector(m, k));
+}
+
+int fus_model_setup_finish(fus_model* m)
+{
+  FUSCHK(external_model(m));
+  return d_setup_finish(m);
+}
+
+int fus_model_stage_begin(fus_model* m, int stage, double t, double dt)
+{
+  FUSCHK(external_model(m));
+  if (!m->initialised || !m->setup_done)
+    return fail(FUS_ERR_STATE, "fus_model_setup_finish and fus_model_init come first");
+  if (stage < 0 || stage >= m->rk_order)
+    return fail(FUS_ERR_ARG, "stage out of range");
+  FUSCHK(d_stage_begin(m, stage, t, dt));
+  HIPCHK(hipStreamSynchronize(m->ctx->stream));   // the send buffer is complete on return
+  return FUS_OK;
+}
+
+int fus_model_stage_end(fus_model* m, int stage, double t, double dt)
+{
+  FUSCHK(external_model(m));
+  if (stage < 0 || stage >= m->rk_order)
+    return fail(FUS_ERR_ARG, "stage out of range");
+  FUSCHK(d_stage_end(m, stage, t, dt));
+  if (stage == m->rk_order - 1 && m->rk_order != 4)
+    std::swap(m->u_, m->u0), std::swap(m->v_, m->v0);  // the accumulated solution is the new state
   return FUS_OK;
 }
 

@@ -23,7 +23,9 @@ SYMBOLS = [
     "fus_op_set_neighbours", "fus_model_create", "fus_model_destroy", "fus_model_set_rk_order", "fus_model_init", "fus_model_rk4",
     "fus_model_rk4_steps", "fus_model_get", "fus_model_set", "fus_model_get_mass", "fus_model_ndofs",
     "fus_profile_enable", "fus_profile_get", "fus_layout_check", "fus_layout_check_ex", "fus_comm_init_local",
-    "fus_group_finish_setup", "fus_group_rk4_steps",
+    "fus_group_finish_setup", "fus_group_rk4_steps", "fus_op_halo_layout", "fus_op_halo_buffers",
+    "fus_model_setup_count", "fus_model_setup_pack", "fus_model_setup_unpack", "fus_model_setup_finish",
+    "fus_model_stage_begin", "fus_model_stage_end",
 ]
 
 
@@ -116,6 +118,13 @@ class Context:
         buf = (C.c_char * 128)()
         check(lib().fus_comm_unique_id(buf))
         return bytes(buf)
+
+    def init_external(self, rank: int, nranks: int):
+        """External transport: the caller exchanges the packed interface values itself (GPU-aware MPI in
+        the reference's setting); see fusmi.h.  No RCCL communicator is created."""
+        self.set_option("external_transport", 1)
+        check(lib().fus_comm_init(self.h, C.c_int(rank), C.c_int(nranks), None))
+        self.rank, self.nranks = rank, nranks
 
     @staticmethod
     def init_local_group(ctxs):

@@ -54,6 +54,25 @@ class _SpectralExplicit:
         self.u_n = Function(self.V, dt_)
         self.v_n = Function(self.V, dt_)
 
+    # ---- external transport (the caller exchanges the interface values; fusmi.h) ----
+    def setup_count(self) -> int:
+        return int(lib().fus_model_setup_count(self.h))
+
+    def setup_pack(self, k: int):
+        check(lib().fus_model_setup_pack(self.h, C.c_int(k)))
+
+    def setup_unpack(self, k: int):
+        check(lib().fus_model_setup_unpack(self.h, C.c_int(k)))
+
+    def setup_finish(self):
+        check(lib().fus_model_setup_finish(self.h))
+
+    def stage_begin(self, i: int, t: float, dt: float):
+        check(lib().fus_model_stage_begin(self.h, C.c_int(i), C.c_double(t), C.c_double(dt)))
+
+    def stage_end(self, i: int, t: float, dt: float):
+        check(lib().fus_model_stage_end(self.h, C.c_int(i), C.c_double(t), C.c_double(dt)))
+
     def init(self):
         """u_n = v_n = 0 (_linear.py:363-369, Linear.hpp:161-164)."""
         self.u_n.x.array[:] = 0.0

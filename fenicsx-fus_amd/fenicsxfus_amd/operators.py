@@ -112,6 +112,20 @@ class SpectralOperatorData:
         check(lib().fus_facet_diag(self.h, C.c_int64(len(cells)), ptr(cells), ptr(lf), ptr(cc), ptr(out)))
         return out
 
+    def halo_layout(self):
+        """External transport: (ranks, counts, offsets) of the neighbours in buffer order (values)."""
+        n = C.c_int()
+        check(lib().fus_op_halo_layout(self.h, C.byref(n), None, None, None))
+        ranks, counts, offs = np.zeros(n.value, np.int32), np.zeros(n.value, np.int64), np.zeros(n.value, np.int64)
+        check(lib().fus_op_halo_layout(self.h, C.byref(n), ptr(ranks), ptr(counts), ptr(offs)))
+        return ranks, counts, offs
+
+    def halo_buffers(self):
+        """External transport: device addresses of the send / receive buffers and their length in values."""
+        s, r, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(lib().fus_op_halo_buffers(self.h, C.byref(s), C.byref(r), C.byref(n)))
+        return s.value, r.value, n.value
+
     def close(self):
         if self.h:
             lib().fus_op_destroy(self.h)

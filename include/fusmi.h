@@ -59,6 +59,7 @@ int fus_synchronize(fus_ctx* ctx);
  * forms -- absorbing and delta-mass terms on every listed boundary facet (BM7-SC1/forms.py:37-42),
  * source doubled (Lossy.hpp:216-220); 1 the Python package's -- those terms on tag 2 only, source
  * not doubled (python/src/fenicsxfus/_lossy.py:107-128, :186-189).
+ * "external_transport" (1, before fus_comm_init: the caller exchanges the interface values, see below).
  * Multi-rank, set before fus_comm_init / fus_model_create: "overlap_blocks" (1: the blocks touching
  * interface DOFs are launched first and the exchange overlaps the remaining blocks; default 0: it
  * overlaps the shared-DOF kernel only), "halo_loopback" (1: timing rehearsal on one GPU -- a 1-rank
@@ -192,6 +193,30 @@ int64_t fus_model_ndofs(fus_model* model); /* number_of_dofs(), Linear.hpp:318 (
 
 int fus_group_finish_setup(fus_model** models, int n);
 int fus_group_rk4_steps(fus_model** models, int n, double t0, double dt, int64_t nsteps);
+
+/* ---- external transport ---------------------------------------------------------------------
+ * For callers that move the interface values themselves -- GPU-aware MPI in the reference's setting
+ * (its scatter_fwd/scatter_rev, Linear.hpp:196-206, are MPI neighbourhood exchanges) -- instead of
+ * the built-in RCCL exchange.  fus_set_option(ctx, "external_transport", 1), then
+ * fus_comm_init(ctx, rank, nranks, NULL), fus_op_create, fus_op_set_neighbours, fus_model_create.
+ *   fus_op_halo_layout   neighbours in the order of the buffers: rank, number of values, offset (values)
+ *   fus_op_halo_buffers  device pointers of the send / receive buffers (element type T) and their length;
+ *                        neighbour k sends send[off_k .. off_k + count_k) and receives into the same
+ *                        range of recv
+ * Setup (once): for k in [0, fus_model_setup_count): fus_model_setup_pack(k) -> exchange ->
+ * fus_model_setup_unpack(k); then fus_model_setup_finish, fus_model_init.
+ * Every RK stage i of a step at time t: fus_model_stage_begin(i, t, dt) -> exchange ->
+ * fus_model_stage_end(i, t, dt).  *_pack / stage_begin return with the send buffer complete; the
+ * receive buffer must be complete when *_unpack / stage_end are called.  Every sharer adds the ranks'
+ * values in ascending rank order, so all of them end with identical bits. */
+int fus_op_halo_layout(fus_op* op, int* nneigh, int32_t* ranks, int64_t* counts, int64_t* offsets);
+int fus_op_halo_buffers(fus_op* op, void** send_dev, void** recv_dev, int64_t* nvalues);
+int fus_model_setup_count(fus_model* model);
+int fus_model_setup_pack(fus_model* model, int k);
+int fus_model_setup_unpack(fus_model* model, int k);
+int fus_model_setup_finish(fus_model* model);
+int fus_model_stage_begin(fus_model* model, int stage, double t, double dt);
+int fus_model_stage_end(fus_model* model, int stage, double t, double dt);
 
 /* ---- measurement -----------------------------------------------------------------------------
  * HIP-event timing of the library's own kernels on the stream they run on.  Names:

@@ -339,3 +339,91 @@ def test_general_partition_four_quadrants_gpu(orc):
         mdl.close()
     for cx in ctxs:
         cx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model_kind", ["linear", "westervelt"])
+def test_external_transport_gpu(orc, model_kind):
+    """The external-transport entry points (what a GPU-aware-MPI caller uses instead of the built-in
+    RCCL exchange): three slab ranks on one GPU, the exchange done HERE by device-to-device copies
+    between the ranks' send / receive buffers, the stage and setup halves driven one by one."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    size, nsteps = 3, NSTEPS
+    pr = Problem(orc, N_GLOBAL, P, hi=HI, perturb=0.1)
+    c, rho = material(pr.mesh)
+    gt = fa.tag_box_boundary(pr.mesh)
+    dt = dt_value()
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    w0 = 2 * np.pi * F0
+    delta = np.where(c > 2000.0, fa.compute_diffusivity_of_sound(w0, 2800.0, 46.0), fa.compute_diffusivity_of_sound(w0, 1500.0, 0.2))
+    beta = np.where(c > 2000.0, 6.0, 3.5)
+    p0 = P0 if model_kind == "linear" else 100 * P0
+    if model_kind == "linear":
+        m, src, absb, coeff = pr.linear_model_vectors(c, rho, gt)
+        orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, F0, p0, S0, 0.0, nsteps * dt * (1 + 1e-12), dt, u, v)
+    else:
+        m, src, absb, src2, lin, att = pr.lossy_model_vectors(c, rho, delta, gt)
+        n1 = -2.0 * beta / rho**2 / c**4
+        orc.westervelt_rk4(3, pr.N, pr.dm, pr.G, pr.detJ, pr.D, lin, att, n1, -n1, m, src, absb, src2, F0, p0, S0,
+                           0.0, nsteps * dt * (1 + 1e-12), dt, u, v)
+    ctxs, models, offs = [], [], []
+    for r in range(size):
+        cx = fa.Context(0)
+        cx.init_external(r, size)
+        mesh = fa.BoxMesh([0, 0, 0], HI, N_GLOBAL, rank=r, size=size, perturb=0.1)
+        V = fa.FunctionSpace(mesh, P)
+        cr, rr = material(mesh)
+        cxr = mesh.cell_centroids()[:, 0]
+        if model_kind == "linear":
+            mdl = fa.LinearSpectralExplicit(mesh, fa.tag_box_boundary(mesh), P, cr, rr, F0, p0, S0, 4, dt, V=V, ctx=cx)
+        else:
+            dr = np.where(cr > 2000.0, delta.max(), delta.min())
+            br = np.where(cr > 2000.0, 6.0, 3.5)
+            mdl = fa.WesterveltSpectralExplicit(mesh, fa.tag_box_boundary(mesh), P, cr, rr, dr, br, F0, p0, S0, 4, dt,
+                                                V=V, ctx=cx)
+        ctxs.append(cx), models.append(mdl), offs.append(V.global_offset)
+    layouts = [mdl.data.halo_layout() for mdl in models]
+    bufs = [mdl.data.halo_buffers() for mdl in models]
+    assert [len(l[0]) for l in layouts] == [1, 2, 1]
+
+    def exchange():
+        """rank r's send range for neighbour q -> q's receive range for neighbour r (8-byte values)."""
+        for r in range(size):
+            for q, cnt, off in zip(*layouts[r]):
+                k = list(layouts[q][0]).index(r)
+                assert layouts[q][1][k] == cnt
+                rc = hip.hipMemcpy(bufs[q][1] + 8 * int(layouts[q][2][k]), bufs[r][0] + 8 * int(off), 8 * int(cnt), 3)
+                assert rc == 0
+
+    for k in range(models[0].setup_count()):
+        for mdl in models:
+            mdl.setup_pack(k)
+        exchange()
+        for mdl in models:
+            mdl.setup_unpack(k)
+    for mdl in models:
+        mdl.setup_finish()
+        mdl.init()
+    t = 0.0
+    for _ in range(nsteps):
+        for i in range(4):
+            for mdl in models:
+                mdl.stage_begin(i, t, dt)
+            exchange()
+            for mdl in models:
+                mdl.stage_end(i, t, dt)
+        t += dt
+    for r, mdl in enumerate(models):
+        k = mdl.data.ndofs
+        assert np.abs(mdl.mass_vector() - m[offs[r]:offs[r] + k]).max() < 1e-14 * np.abs(m).max()
+        assert np.abs(u).max() > 0
+        assert np.abs(mdl.u_sol().x.array - u[offs[r]:offs[r] + k]).max() < 1e-10 * np.abs(u).max()
+        assert np.abs(mdl.v_n.x.array - v[offs[r]:offs[r] + k]).max() < 1e-10 * np.abs(v).max()
+    with pytest.raises(fa.FusError):                     # the built-in loop refuses: no transport of its own
+        models[0].rk4_steps(0.0, dt, 1)
+    for mdl in models:
+        mdl.close()
+    for cx in ctxs:
+        cx.close()

@@ -89,6 +89,38 @@ def cpu_baseline(P, n, steps):
             "single_thread_value": nd * n1 / el1}
 
 
+class _DevBuf:
+    """A raw device buffer as seen by torch (``__cuda_array_interface__``), no copy."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def torch_exchange(torch, dist, model, rank, loopback=False):
+    """exchange() for the external transport: neighbour ranges of the library's send buffer go to the
+    neighbours' receive buffers with torch.distributed P2P (NCCL = RCCL); loopback: to the own one."""
+    ranks, counts, offs = model.data.halo_layout()
+    sp, rp, n = model.data.halo_buffers()
+    if n == 0:
+        return lambda: None
+    ts = "<f8" if model.data.dtype == np.float64 else "<f4"
+    send = torch.as_tensor(_DevBuf(sp, n, ts), device="cuda")
+    recv = torch.as_tensor(_DevBuf(rp, n, ts), device="cuda")
+
+    def exchange():
+        if loopback:
+            recv.copy_(send)
+        else:
+            ops = []
+            for q, c, o in zip(ranks.tolist(), counts.tolist(), offs.tolist()):
+                ops.append(dist.P2POp(dist.irecv, recv[o:o + c], q))
+                ops.append(dist.P2POp(dist.isend, send[o:o + c], q))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        torch.cuda.synchronize()
+    return exchange
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,10 +140,20 @@ def main():
                     help="diagnostic: time the middle slab of 3 with its RCCL exchange looped back to this GPU "
                          "(exchange overhead rehearsal on one GPU; the solution is not the physical one)")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no per-kernel HIP events in the timed region")
+    ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
+                    help="N > 1 exchange: the library's RCCL send/recv (default; falls back to 'torch' if its "
+                         "communicator cannot be created) or torch.distributed P2P through the external-transport "
+                         "entry points (slower: the host drives every stage half)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-n", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=400)
     args = ap.parse_args()
+
+    # stdout carries exactly one line, the JSON result: whatever libraries print on file descriptor 1
+    # (RCCL's start-up banner under torch.distributed.run, for one) is sent to stderr instead
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
 
@@ -131,21 +173,36 @@ def main():
 
     ctx = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves, deterministic=args.deterministic, geometry=args.geometry)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run
+    transport = args.transport
     if args.halo_loopback:
         assert world == 1 and not launched
-        ctx.set_option("halo_loopback", 1)
-        ctx.comm_init(1, 3, fa.Context.unique_id())
+        if transport == "torch":
+            ctx.init_external(1, 3)
+        else:
+            ctx.set_option("halo_loopback", 1)
+            ctx.comm_init(1, 3, fa.Context.unique_id())
         args.both_geometries = 0
     if world > 1 or launched:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        ids = [fa.Context.unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        ctx.comm_init(rank, world, ids[0])
-        ids2 = [fa.Context.unique_id() if rank == 0 else None]   # communicator of the secondary run
-        dist.broadcast_object_list(ids2, src=0)
+        ids2 = [None]
+        if transport == "rccl":
+            try:
+                ids = [fa.Context.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                ctx.comm_init(rank, world, ids[0])
+                ids2 = [fa.Context.unique_id() if rank == 0 else None]   # communicator of the secondary run
+                dist.broadcast_object_list(ids2, src=0)
+            except fa.FusError as e:            # the library's own RCCL communicator could not be made
+                print(f"[bench rank {rank}] RCCL transport unavailable ({e}); using torch.distributed P2P", file=sys.stderr)
+                transport = "torch"
+                ctx = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves,
+                                 deterministic=args.deterministic, geometry=args.geometry)
+        if transport == "torch":
+            ctx.init_external(rank, world)
+            args.both_geometries = 0
 
     def barrier():
         if world > 1 or launched:
@@ -166,15 +223,25 @@ def main():
         """Build the model on `context`, run warmup + timed steps; returns timings and model info."""
         model = fa.LinearSpectralExplicit(mesh, tags, P, np.full(nc, c0), np.full(nc, rho0), freq, p0, c0, 4, dt,
                                           V=V, ctx=context)
+        if transport == "torch" and (world > 1 or args.halo_loopback):
+            # external transport: the host drives the two halves of every stage around a torch P2P exchange
+            exch = torch_exchange(torch, dist if world > 1 else None, model, rank, loopback=args.halo_loopback)
+            model.external_setup(exch)
+
+            def advance(t, n):
+                model.external_rk_steps(t, dt, n, exch)
+        else:
+            def advance(t, n):
+                model.rk4_steps(t, dt, n, sync=False)
         model.init()
         info = model.data.info()
         affine = model.data.is_affine()
-        model.rk4_steps(0.0, dt, warmup)
+        advance(0.0, warmup)
         if profile:
             context.profile_enable(2)      # HIP events around the dominant kernel only (see fusmi.h)
         barrier()
         t0 = time.perf_counter()
-        model.rk4_steps(warmup * dt, dt, steps, sync=False)
+        advance(warmup * dt, steps)
         barrier()
         elapsed = time.perf_counter() - t0
         if world > 1 or launched:
@@ -187,7 +254,7 @@ def main():
             # per-kernel breakdown of a step: separate, untimed pass with events around every kernel
             nb = min(steps, 5)
             context.profile_enable(1)
-            model.rk4_steps((warmup + steps) * dt, dt, nb)
+            advance((warmup + steps) * dt, nb)
             context.synchronize()
             prof["breakdown_ms_per_step"] = {k: context.profile_get(k)[0] / nb for k in
                                              ("stiffness", "stiffness_if", "shared", "boundary", "stage", "halo")}
@@ -257,8 +324,9 @@ def main():
                                      "(BASELINE.json configs[2])" if (n, P, args.dtype) == (128, 7, "f64") else
                                      "(parity/diagnostic configuration)"), "ndofs_global": int(ndofs_global),
                        "cells_per_gpu": int(nc), "geometry": "affine (7 fp64 per cell, B_affine)" if affine else "general (G streamed, 6 fp64 per point, B_general)",
-                       "partition": "middle x-slab of 3, RCCL exchange looped back (diagnostic)" if args.halo_loopback
-                       else f"x-slabs x{world}", "blocks": info["nblocks"],
+                       "partition": "middle x-slab of 3, exchange looped back (diagnostic)" if args.halo_loopback
+                       else f"x-slabs x{world}", "transport": transport if (world > 1 or args.halo_loopback) else "none",
+                       "blocks": info["nblocks"],
                        "lds_bytes_per_block": info["lds_bytes"], "dt": dt},
             "roofline": {"bound": "hbm", "kernel": f"k_block_op<{'double' if args.dtype == 'f64' else 'float'},{P},stiffness,+fused RK4 stage>", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
@@ -284,7 +352,7 @@ def main():
                                      "frac_of_8TBps": b2 * v2 / world / 8e12, "finite_nonzero_solution": fin2}
         if not args.no_cpu and args.dtype == "f64" and world == 1:   # CPU leg on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(P, args.cpu_n, args.cpu_steps)
-        print(json.dumps(out))
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or launched:
         dist.barrier()
         dist.destroy_process_group()

@@ -108,6 +108,26 @@ class _SpectralExplicit:
         if sync:
             self.ctx.synchronize()
 
+    def external_setup(self, exchange):
+        """External transport, setup phase: sums the lumped mass (and Westervelt's mass diagonal) over
+        the sharers through ``exchange()``, a callable that moves every neighbour's range of the send
+        buffer into the matching range of the neighbour's receive buffer (see fusmi.h)."""
+        for k in range(self.setup_count()):
+            self.setup_pack(k)
+            exchange()
+            self.setup_unpack(k)
+        self.setup_finish()
+
+    def external_rk_steps(self, t0: float, dt: float, nsteps: int, exchange, rk_order: int = 4):
+        """External transport: nsteps steps with the two halves of every stage around ``exchange()``."""
+        t = t0
+        for _ in range(nsteps):
+            for i in range(rk_order):
+                self.stage_begin(i, t, dt)
+                exchange()
+                self.stage_end(i, t, dt)
+            t += dt
+
     def u_sol(self):
         self._pull()
         return self.u_n

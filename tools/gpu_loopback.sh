@@ -2,7 +2,7 @@
 # usage: gpu_loopback.sh [lib name]  -- RK4 step with and without the looped-back RCCL exchange
 [ -n "$1" ] && export FUSMI_LIB=$PWD/abl/libfusmi_$1.so
 for a in "--both-geometries 0" "--halo-loopback" "--both-geometries 0 --no-profile" "--halo-loopback --no-profile"; do
-  timeout -k 10 300 python bench.py --no-cpu --steps 20 --warmup 3 $a > gpurun_out/bench_lb.log 2>&1
+  timeout -k 10 300 python bench.py --no-cpu --steps 20 --warmup 3 $a > gpurun_out/bench_lb.log 2> gpurun_out/bench_lb.err
   tail -1 gpurun_out/bench_lb.log | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())

@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: gpu_quick.sh [bench args]   -- GPU tests + short bench summary (run through gpurun)
-timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2>&1; tail -3 gpurun_out/gpu_tests.log
-timeout -k 10 300 python bench.py --no-cpu "$@" > gpurun_out/bench_quick.log 2>&1
+timeout -k 10 600 python -m pytest tests -m gpu -x -q > gpurun_out/gpu_tests.log 2> gpurun_out/gpu_tests.err; tail -3 gpurun_out/gpu_tests.log
+timeout -k 10 300 python bench.py --no-cpu "$@" > gpurun_out/bench_quick.log 2> gpurun_out/bench_quick.err
 tail -1 gpurun_out/bench_quick.log | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())

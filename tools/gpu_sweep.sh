@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: gpu_sweep.sh "args1" "args2" ...  -- one short bench per argument string
 for a in "$@"; do
-  timeout -k 10 300 python bench.py --no-cpu --steps 10 --warmup 2 $a > gpurun_out/bench_sweep.log 2>&1
+  timeout -k 10 300 python bench.py --no-cpu --steps 10 --warmup 2 $a > gpurun_out/bench_sweep.log 2> gpurun_out/bench_sweep.err
   tail -1 gpurun_out/bench_sweep.log | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())

@@ -4,7 +4,7 @@
 args="$1"; shift
 for name in "$@"; do
   export FUSMI_LIB=$PWD/abl/libfusmi_$name.so
-  timeout -k 10 300 python bench.py --no-cpu --steps 10 --warmup 2 $args > gpurun_out/bench_var_$name.log 2>&1
+  timeout -k 10 300 python bench.py --no-cpu --steps 10 --warmup 2 $args > gpurun_out/bench_var_$name.log 2> gpurun_out/bench_var_$name.err
   tail -1 gpurun_out/bench_var_$name.log | python -c "
 import sys,json
 d=json.loads(sys.stdin.read())

@@ -14,6 +14,5 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $out/pmc_$ctr -- python3 bench.py --no-cpu --steps 4 --warmup 1 --both-geometries 0 > $out/pmc_$ctr.log 2>&1 || { tail -5 $out/pmc_$ctr.log; exit 1; }
   echo "pmc $ctr done"
 done
-timeout -k 10 600 python bench.py --steps 20 --warmup 3 > $out/bench.log 2>&1 || { tail -5 $out/bench.log; exit 1; }
-tail -1 $out/bench.log > $out/bench.json
+timeout -k 10 600 python bench.py --steps 20 --warmup 3 > $out/bench.json 2> $out/bench.err || { tail -5 $out/bench.err; exit 1; }
 python tools/make_profile_summary.py $tag

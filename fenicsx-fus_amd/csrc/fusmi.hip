@@ -217,7 +217,7 @@ struct fus_model
   void* mn1 = nullptr;      // Westervelt: diag of M(-2 beta/(rho^2 c^4)), internal numbering
   // boundary dofs (diagonal source / absorbing weights), sorted by internal index:
   // [0, nb_int) are block-interior (applied in the fused epilogue through d_blk_bnd_off),
-  // [nb_int, nb) are shared dofs (applied by k_boundary after the partial sums are reduced)
+  // [nb_int, nb) are shared dofs (their terms ride in pseudo partial slots: boundary_next / k_boundary_partial)
   int64_t nb = 0, nb_int = 0;
   int32_t* d_bidx = nullptr;
   int32_t* d_blk_bnd_off = nullptr;

@@ -1026,20 +1026,6 @@ __global__ void k_boundary_partial(int64_t nb, const int32_t* __restrict__ idx,
   }
 }
 
-// Diagonal boundary terms (Linear.hpp:205 with forms.py:38-39 collocated at GLL nodes):
-// b[idx] += g(t) * srcw - absw * vn[idx]
-template <typename T>
-__global__ void k_boundary(int64_t nb, const int32_t* __restrict__ idx, const T* __restrict__ srcw,
-                           const T* __restrict__ absw, T gval, const T* __restrict__ vn,
-                           T* __restrict__ b)
-{
-  const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= nb)
-    return;
-  const int32_t i = idx[k];
-  b[i] += gval * srcw[k] - absw[k] * vn[i];
-}
-
 // ---------------------------------------------------------------------------------------------
 // Setup / plumbing kernels
 // ---------------------------------------------------------------------------------------------

@@ -139,6 +139,8 @@ def main():
     ap.add_argument("--halo-loopback", action="store_true",
                     help="diagnostic: time the middle slab of 3 with its RCCL exchange looped back to this GPU "
                          "(exchange overhead rehearsal on one GPU; the solution is not the physical one)")
+    ap.add_argument("--model", choices=["linear", "lossy", "westervelt"], default="linear",
+                    help="linear is BASELINE's metric; lossy / westervelt (SURVEY 8f-1) are reported as diagnostics")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no per-kernel HIP events in the timed region")
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
                     help="N > 1 exchange: the library's RCCL send/recv (default; falls back to 'torch' if its "
@@ -221,8 +223,17 @@ def main():
 
     def run(context, steps, warmup, profile):
         """Build the model on `context`, run warmup + timed steps; returns timings and model info."""
-        model = fa.LinearSpectralExplicit(mesh, tags, P, np.full(nc, c0), np.full(nc, rho0), freq, p0, c0, 4, dt,
-                                          V=V, ctx=context)
+        if args.model == "linear":
+            model = fa.LinearSpectralExplicit(mesh, tags, P, np.full(nc, c0), np.full(nc, rho0), freq, p0, c0, 4, dt,
+                                              V=V, ctx=context)
+        else:   # attenuating, weakly nonlinear water-like medium (BM7-SC1/main.cpp:43-46 style coefficients)
+            delta = np.full(nc, fa.compute_diffusivity_of_sound(2 * np.pi * freq, c0, 0.2))
+            if args.model == "lossy":
+                model = fa.LossySpectralExplicit(mesh, tags, P, np.full(nc, c0), np.full(nc, rho0), delta, freq, p0, c0,
+                                                 4, dt, V=V, ctx=context)
+            else:
+                model = fa.WesterveltSpectralExplicit(mesh, tags, P, np.full(nc, c0), np.full(nc, rho0), delta,
+                                                      np.full(nc, 3.5), freq, p0, c0, 4, dt, V=V, ctx=context)
         if transport == "torch" and (world > 1 or args.halo_loopback):
             # external transport: the host drives the two halves of every stage around a torch P2P exchange
             exch = torch_exchange(torch, dist if world > 1 else None, model, rank, loopback=args.halo_loopback)
@@ -289,10 +300,13 @@ def main():
         # stage update for the block-interior DOFs it completes (the shared DOFs' update runs in
         # k_stage on the shared range).
         # B_general streams 6 s of G per element-DOF; B_affine rebuilds G from per-cell numbers
-        b_stiff = rho_e * (s + 4 + (0 if affine else 6 * s)) + s
-        b_general = 4 * (b_stiff + 12 * s)
+        # lossy / Westervelt: one more gathered operator input, Westervelt two more vector reads
+        extra_x = {"linear": 0, "lossy": 1, "westervelt": 1}[args.model]
+        extra_v = {"linear": 0, "lossy": 0, "westervelt": 2}[args.model]
+        b_stiff = rho_e * (s + 4 + (0 if affine else 6 * s) + extra_x * s) + s
+        b_general = 4 * (b_stiff + (12 + extra_v) * s)
         n_int = info["interior_dofs"]
-        alg_launch = b_stiff * ndl + 12 * s * n_int
+        alg_launch = b_stiff * ndl + (12 + extra_v) * s * n_int
         # N > 1: the stage's block kernel runs as two launches (interface blocks first, then the rest)
         k_ms, k_cnt = prof["stiffness"][0] + prof["stiffness_if"][0], prof["stiffness"][1]
         avg_ms = k_ms / max(k_cnt, 1)
@@ -307,7 +321,8 @@ def main():
                 and not args.deterministic and not affine):
             traffic = json.load(open(pmc))["k_block_op_fused"]["hbm_bytes_per_launch"]
         out = {
-            "metric": "DOF-updates/sec (RK4 step) at p=4 hex fp64" if (P == 4 and args.dtype == "f64") else f"DOF-updates/sec (RK4 step) at p={P} hex {args.dtype}",
+            "metric": ("DOF-updates/sec (RK4 step) at p=4 hex fp64" if (P == 4 and args.dtype == "f64") else
+                       f"DOF-updates/sec (RK4 step) at p={P} hex {args.dtype}") + ("" if args.model == "linear" else f" [{args.model} model]"),
             "value": value,
             "unit": "DOF-updates/s",
             "n_gpus": world,
@@ -319,7 +334,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"3D homogeneous wave, {n}^3 hex p={P} {args.dtype} per GPU, Linear RK4 "
+            "config": {"workload": f"3D homogeneous wave, {n}^3 hex p={P} {args.dtype} per GPU, {args.model.capitalize()} RK4 "
                                    + ("(BASELINE.json configs[1])" if (n, P, args.dtype) == (64, 4, "f64") else
                                      "(BASELINE.json configs[2])" if (n, P, args.dtype) == (128, 7, "f64") else
                                      "(parity/diagnostic configuration)"), "ndofs_global": int(ndofs_global),
@@ -344,7 +359,7 @@ def main():
         }
         if other is not None:
             e2, aff2, fin2 = other
-            b2 = 4 * (rho_e * (s + 4 + (0 if aff2 else 6 * s)) + s + 12 * s)
+            b2 = 4 * (rho_e * (s + 4 + (0 if aff2 else 6 * s) + extra_x * s) + s + (12 + extra_v) * s)
             v2 = ndofs_global * args.steps / e2
             out["other_geometry"] = {"geometry": "affine (7 fp64 per cell, B_affine)" if aff2 else
                                      "general (G streamed, B_general)", "value": v2, "unit": "DOF-updates/s",

@@ -1448,7 +1448,11 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   // path (profiles/r01_block_sweep.txt)
   // quadrilaterals: N^2 nodes per element, so many more elements make a block of that size
   static const int be_quad[8] = {0, 0, 512, 256, 256, 128, 128, 64};
-  const int be_stream = op->tdim == 2 ? be_quad[op->P] : (op->P == 2 ? 128 : (op->P == 3 ? 64 : 32));
+  // fp32 halves the LDS per dof: there the best sizes keep two or three blocks per CU resident
+  // (p=4: 48, p=5/6: 24, p=7: 16 -- +8 / +15 / +45 / +42 % over 32 elements, profiles/r01_block_sweep.txt)
+  static const int be_hex_f32[8] = {0, 0, 128, 64, 48, 24, 24, 16};
+  const int be_hex = op->dtype == FUS_F32 ? be_hex_f32[op->P] : (op->P == 2 ? 128 : (op->P == 3 ? 64 : 32));
+  const int be_stream = op->tdim == 2 ? be_quad[op->P] : be_hex;
   const int be0 = c->block_elems > 0 ? c->block_elems : (affine_mesh ? be_stream / 2 : be_stream);
   int waves = c->waves > 0 ? c->waves : 4;
   if (op->P > 4 && waves > 4)

@@ -1453,16 +1453,25 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   static const int be_hex_f32[8] = {0, 0, 128, 64, 48, 24, 24, 16};
   const int be_hex = op->dtype == FUS_F32 ? be_hex_f32[op->P] : (op->P == 2 ? 128 : (op->P == 3 ? 64 : 32));
   const int be_stream = op->tdim == 2 ? be_quad[op->P] : be_hex;
-  const int be0 = c->block_elems > 0 ? c->block_elems : (affine_mesh ? be_stream / 2 : be_stream);
+  // fp64, p >= 5, streamed geometry, LDS-atomic mode: the block kernel keeps ONE geometry register
+  // set there (kernels.hpp, FUS_PF1) and fits two waves per SIMD, which pays only if two blocks per
+  // CU are resident: blocks of at most 80 KB of LDS (20 / 12 / 8 elements at p = 5 / 6 / 7 with one
+  // operator input, fewer with two).  +50 / +30 / +35 % over one 32->16-element block per CU.
+  const bool two_per_cu = op->dtype == FUS_F64 && op->tdim == 3 && op->P >= 5 && !affine_mesh
+                          && !op->deterministic && c->block_elems <= 0;
+  static const int be_two[8] = {0, 0, 0, 0, 0, 20, 12, 8};
+  const int be0 = c->block_elems > 0 ? c->block_elems
+                                     : (two_per_cu ? be_two[op->P] : (affine_mesh ? be_stream / 2 : be_stream));
+  const size_t lds_cap = two_per_cu ? 80 * 1024 : 160 * 1024;
   int waves = c->waves > 0 ? c->waves : 4;
   if (op->P > 4 && waves > 4)
     waves = 4;  // launch bound of the block kernel for the higher degrees
-  // blocks must fit the CU's 160 KB of LDS: halve the block size until they do
-  for (int be = be0;; be = (be + 1) / 2)
+  // blocks must fit the LDS budget (the CU's 160 KB, or half of it): shrink the block until they do
+  for (int be = be0;; be = two_per_cu && be > 4 ? be - std::max(1, be / 4) : (be + 1) / 2)
   {
     std::string err = build_layout(op->L, op->P, op->ncells, op->ndofs, op->h_dofmap.data(),
                                    cen.data(), be, waves, force_shared, op->tdim);
-    const bool too_big = err.empty() ? op->L.lds_bytes(op->ts, op->nfields) + 64 > 160 * 1024
+    const bool too_big = err.empty() ? op->L.lds_bytes(op->ts, op->nfields) + 64 > lds_cap
                                      : err.find("65535") != std::string::npos;
     if (too_big && be > 1)
       continue;

@@ -420,6 +420,161 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
   }
 }
 
+// The stiffness pass of elem_compute in two halves, for the single-register-set schedule of the
+// degrees 5 and 6 (k_block_op, PF1): elem_stiff_fwd ends with the transform -- the last reader of in.g --,
+// the kernel then requests the next element's geometry into the same registers, and elem_stiff_bwd
+// does the transposed contractions and the scatter.  Same arithmetic in the same order as
+// elem_compute.
+// DL = 1 (degree 7): the lane's rows / columns of the derivative table are read from LDS (D_l) at the
+// start of each half instead of living in registers for the whole kernel.
+template <typename T, int N, int NF, int DL = 0>
+__device__ __forceinline__ bool elem_stiff_fwd(const ElemIn<T, N, OP_STIFFNESS, GEOM_STREAM>& in,
+                                               const DTab<T, N>& Dk, const T (&Drb_)[N], const T (&Drc_)[N],
+                                               const T* __restrict__ D_l,
+                                               const T* __restrict__ x_l, T* __restrict__ sA,
+                                               const uint16_t* __restrict__ ldm_l,
+                                               const T* __restrict__ cf_l, const T* __restrict__ x2_l,
+                                               const T* __restrict__ cf2_l, int p, int b, int c,
+                                               int (&li)[N], T (&F0)[N], T (&F1)[N], T (&F2)[N])
+{
+  constexpr int N2 = N * N, Nd = N * N * N;
+  constexpr int VW = GLoad<T, N>::VW;
+  if (in.er < 0)
+    return false;
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    li[a] = ldm_l[in.er * Nd + a * N2 + p];
+  const T cf = (NF == 2) ? T(1) : cf_l[in.er];
+  T X[N];
+  if (NF == 2)
+  {
+    const T c1 = cf_l[in.er], c2 = cf2_l[in.er];
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      X[a] = c1 * x_l[li[a]] + c2 * x2_l[li[a]];
+  }
+  else
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      X[a] = x_l[li[a]];
+  }
+#pragma unroll
+  for (int q = 0; q < N; ++q)
+  {
+    T acc = T(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      acc += Dk.d[q * N + i] * X[i];
+    F0[q] = acc;
+  }
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    sA[a * N2 + p] = X[a];
+  T Drb[N], Drc[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+  {
+    Drb[j] = DL ? D_l[b * N + j] : Drb_[j];
+    Drc[j] = DL ? D_l[c * N + j] : Drc_[j];
+  }
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+  {
+    T f1 = T(0), f2 = T(0);
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+    {
+      f1 += Drb[j] * sA[a * N2 + j * N + c];
+      f2 += Drc[j] * sA[a * N2 + b * N + j];
+    }
+    F1[a] = f1;
+    F2[a] = f2;
+  }
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+  {
+    T G6[6];
+#pragma unroll
+    for (int gi = 0; gi < 6; ++gi)
+    {
+      const int v = gi * N + a;
+      G6[gi] = in.g[v / VW][v % VW];
+    }
+    const T w0 = F0[a], w1 = F1[a], w2 = F2[a];
+    F0[a] = cf * (G6[0] * w0 + G6[1] * w1 + G6[2] * w2);
+    F1[a] = cf * (G6[1] * w0 + G6[3] * w1 + G6[4] * w2);
+    F2[a] = cf * (G6[2] * w0 + G6[4] * w1 + G6[5] * w2);
+  }
+  return true;
+}
+
+template <typename T, int N, int DL = 0>
+__device__ __forceinline__ void elem_stiff_bwd(const DTab<T, N>& Dk, const T (&Dcb_)[N], const T (&Dcc_)[N],
+                                               const T* __restrict__ D_l,
+                                               T* __restrict__ y_l, T* __restrict__ sA, int p, int b,
+                                               int c, const int (&li)[N], const T (&F0)[N],
+                                               const T (&F1)[N], const T (&F2)[N])
+{
+  constexpr int N2 = N * N;
+  T Y[N];
+  T Dcb[N], Dcc[N];
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+  {
+    Dcb[j] = DL ? D_l[j * N + b] : Dcb_[j];
+    Dcc[j] = DL ? D_l[j * N + c] : Dcc_[j];
+  }
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    sA[a * N2 + p] = F1[a];
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+  {
+    T acc = T(0);
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+      acc += Dk.d[q * N + a] * F0[q];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      acc += Dcb[j] * sA[a * N2 + j * N + c];
+    Y[a] = acc;
+  }
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    sA[a * N2 + p] = F2[a];
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+  {
+    T acc = Y[a];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+      acc += Dcc[j] * sA[a * N2 + b * N + j];
+    Y[a] = acc;
+  }
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    __hip_atomic_fetch_add(&y_l[li[a]], Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Single geometry register set (see elem_stiff_fwd): fp64, degrees 5 and 6, streamed geometry,
+// LDS-atomic accumulation.  With two sets those kernels need 290-330 registers, i.e. one wave per
+// SIMD and one block per CU; with one set they fit 256: two waves per SIMD, two blocks per CU.
+#ifdef FUS_NO_PF1  // experiment switch
+#define FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) 0
+#else
+#define FUS_PF1(T, P, OP, ATOMIC, GEOM, TD)                                                         \
+  ((sizeof(T) == 8 && (P) >= 5 && (P) <= FUS_PF1_MAXP && (OP) == OP_STIFFNESS && (ATOMIC) && (GEOM) == GEOM_STREAM && (TD) == 3) ? 1 : 0)
+#ifndef FUS_PF1_MAXP
+#define FUS_PF1_MAXP 7
+#endif
+#endif
+
 // Block operator:  bvec[interior dofs of block] = (A x)[...],  partial[(block, shared slot)] =
 // this block's contribution to a shared dof.  x, bvec in internal numbering.
 // geo = G (6*Nd per element, per-lane vector layout) for OP_STIFFNESS, detJw (Nd per element,
@@ -434,7 +589,9 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 // whole 512-entry register file.
 // TD = 2: the same block machinery for quadrilateral elements (Nd = N^2, GEOM_STREAM only).
 template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3>
-__global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P <= 4 && GEOM == GEOM_AFFINE) ? 4 : 1)
+__global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P <= 4 && GEOM == GEOM_AFFINE)
+                                                            ? 4
+                                                            : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1))
 k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
            const T* __restrict__ geo, const T* __restrict__ coef, const T* __restrict__ x,
            T* __restrict__ bvec, T* __restrict__ partial, const StageArgs<T> S)
@@ -670,10 +827,11 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
 #pragma unroll
   for (int j = 0; j < N; ++j)
   {
-    Drb[j] = (OP == OP_STIFFNESS) ? D_l[b * N + j] : T(0);
-    Drc[j] = (OP == OP_STIFFNESS) ? D_l[c * N + j] : T(0);
-    Dcb[j] = (OP == OP_STIFFNESS) ? D_l[j * N + b] : T(0);
-    Dcc[j] = (OP == OP_STIFFNESS) ? D_l[j * N + c] : T(0);
+    constexpr bool inreg = (OP == OP_STIFFNESS) && !(FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) && P >= 6);
+    Drb[j] = inreg ? D_l[b * N + j] : T(0);
+    Drc[j] = inreg ? D_l[c * N + j] : T(0);
+    Dcb[j] = inreg ? D_l[j * N + b] : T(0);
+    Dcc[j] = inreg ? D_l[j * N + c] : T(0);
   }
   T w3[N];  // w_q = w_a w_b w_c of this lane's points (affine geometry only)
 #pragma unroll
@@ -691,6 +849,21 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
       elem_compute2d<T, N, OP, ATOMIC, NF>(in, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, ldm_l, cf_l,      \
                                            x2_l, cf2_l, p, b, c);                                  \
   } while (0)
+  if constexpr (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD))
+  {
+    for (int r = 0; r < ntrips; ++r)
+    {
+      int li[N];
+      T F0[N], F1[N], F2[N];
+      constexpr int DL = (P >= 6) ? 1 : 0;
+      const bool act = elem_stiff_fwd<T, N, NF, DL>(inA, Dk, Drb, Drc, D_l, x_l, sA, ldm_l, cf_l, x2_l, cf2_l, p, b,
+                                                    c, li, F0, F1, F2);
+      elem_fetch<T, N, OP, GEOM, TD>(inA, elem_of(r + 1), geo, elem_off, p);
+      if (act)
+        elem_stiff_bwd<T, N, DL>(Dk, Dcb, Dcc, D_l, y_l, sA, p, b, c, li, F0, F1, F2);
+    }
+  }
+  else
   for (int r = 0; r < ntrips; r += 2)
   {
     const bool has1 = r + 1 < ntrips;

@@ -584,9 +584,10 @@ __device__ __forceinline__ void elem_stiff_bwd(const DTab<T, N>& Dk, const T (&D
 // :203-221): for the block's interior dofs the sum in LDS is complete, so b never goes to HBM --
 // boundary terms are added in LDS, kv = b * minv, and u_, v_, un', vn' (or the new u0, v0 at stage 3)
 // are written straight from here.  Shared dofs still leave as partial sums.
-// Launch bound: up to 8 waves per workgroup for P <= 4; the higher degrees keep more of the element
-// in registers (beyond 256 per lane) and are limited to 4 waves so one wave per SIMD may use the
-// whole 512-entry register file.
+// Launch bound: up to 8 waves per workgroup for P <= 4; the higher degrees are limited to 4 waves and
+// either use the whole 512-entry register file with one wave per SIMD (two geometry register sets:
+// fp32, affine, deterministic variants) or -- FUS_PF1, fp64 streamed geometry -- keep one set and fit
+// two waves per SIMD.
 // TD = 2: the same block machinery for quadrilateral elements (Nd = N^2, GEOM_STREAM only).
 template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3>
 __global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P <= 4 && GEOM == GEOM_AFFINE)

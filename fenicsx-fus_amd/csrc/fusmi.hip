@@ -1460,8 +1460,12 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   const bool two_per_cu = op->dtype == FUS_F64 && op->tdim == 3 && op->P >= 5 && !affine_mesh
                           && !op->deterministic && c->block_elems <= 0;
   static const int be_two[8] = {0, 0, 0, 0, 0, 20, 12, 8};
+  // affine path: about half the streamed size; at p >= 5 again small enough for two blocks per CU
+  // (12 / 12 / 8: +11 / +51 / +49 % over 16, profiles/r01_block_sweep.txt)
+  static const int be_aff_hi[8] = {0, 0, 0, 0, 0, 12, 12, 8};
+  const int be_affine = (op->tdim == 3 && op->P >= 5) ? be_aff_hi[op->P] : be_stream / 2;
   const int be0 = c->block_elems > 0 ? c->block_elems
-                                     : (two_per_cu ? be_two[op->P] : (affine_mesh ? be_stream / 2 : be_stream));
+                                     : (two_per_cu ? be_two[op->P] : (affine_mesh ? be_affine : be_stream));
   const size_t lds_cap = two_per_cu ? 80 * 1024 : 160 * 1024;
   int waves = c->waves > 0 ? c->waves : 4;
   if (op->P > 4 && waves > 4)

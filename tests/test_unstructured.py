@@ -61,12 +61,13 @@ def test_layout_on_unstructured_mesh(ref_mesh):
 
 
 @pytest.mark.gpu
-def test_reference_operator_test_on_its_own_mesh(orc, ref_mesh):
+@pytest.mark.parametrize("P", [4, 6])
+def test_reference_operator_test_on_its_own_mesh(orc, ref_mesh, P):
     """cpp/fenicsx-sf/tests/test_operators3d/main.cpp with its Gmsh mesh (the commented read_mesh
-    block :40-48): P = 4, u = sin(x) cos(pi y), c0 = 1.5e-3, rho0 = 1e-3, mass coefficient 1/(rho c^2),
+    block :40-48): P = 4 (and 6: the single-register-set kernel on an unstructured mesh),
+    u = sin(x) cos(pi y), c0 = 1.5e-3, rho0 = 1e-3, mass coefficient 1/(rho c^2),
     stiffness coefficient -1/rho; HIP operators vs the oracle, then 10 Linear RK4 steps."""
     mesh, tags = ref_mesh
-    P = 4
     V = HexFunctionSpace(mesh, P)
     n, nc = V.num_dofs, mesh.num_cells
     wts, D = orc.gll_weights_at(V.nodes1d), orc.dphi(V.nodes1d)

@@ -1560,8 +1560,8 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
   }
   else if (!strcmp(key, "waves"))
   {
-    if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8)
-      return fail(FUS_ERR_ARG, "waves must be 0 (auto), 1, 2, 4 or 8");
+    if (value < 0 || value > 8)
+      return fail(FUS_ERR_ARG, "waves must be 0 (auto) or 1..8");
     c->waves = (int)value;
   }
   else if (!strcmp(key, "deterministic"))

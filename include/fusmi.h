@@ -49,7 +49,7 @@ int fus_init(int device, fus_ctx** ctx);
 int fus_finalize(fus_ctx* ctx);
 int fus_synchronize(fus_ctx* ctx);
 /* Tunables, set before fus_op_create: "block_elems" (elements per LDS block) and "waves"
- * (waves per workgroup; 1, 2, 4 or 8): default 0 = auto (hexahedra with G streamed: 128 / 64 / 32 /
+ * (waves per workgroup, 1..8): default 0 = auto (hexahedra with G streamed: 128 / 64 / 32 /
  * 20 / 12 / 8 elements at P = 2..7 in fp64, 128 / 64 / 48 / 24 / 24 / 16 in fp32, about half of
  * that on the affine path; 4 waves), "geometry" (0 auto |
  * 1 always stream the per-point factors), "fields" (1 | 2: operator inputs the block kernel

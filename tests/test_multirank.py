@@ -427,3 +427,42 @@ def test_external_transport_gpu(orc, model_kind):
         mdl.close()
     for cx in ctxs:
         cx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Ph", [5, 7])
+def test_slabs_higher_degree_gpu(orc, Ph):
+    """Two slabs at p = 5 and p = 7: the single-register-set block kernel (fp64, streamed geometry) with
+    interface DOFs, against the single-rank oracle."""
+    n, hi, nsteps, size = (4, 2, 2), [0.016, 0.008, 0.008], 4, 2
+    pr = Problem(orc, n, Ph, hi=hi, perturb=0.1)
+    nc = pr.mesh.num_cells
+    c, rho = np.full(nc, 1500.0), np.full(nc, 1000.0)
+    m, src, absb, coeff = pr.linear_model_vectors(c, rho, fa.tag_box_boundary(pr.mesh))
+    dt = 0.4 * (hi[0] / n[0]) / (1500.0 * Ph**2)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, F0, P0, S0, 0.0, nsteps * dt * (1 + 1e-12), dt, u, v)
+    ctxs = [fa.Context(0) for _ in range(size)]
+    fa.Context.init_local_group(ctxs)
+    models, offs = [], []
+    for r in range(size):
+        mesh = fa.BoxMesh([0, 0, 0], hi, n, rank=r, size=size, perturb=0.1)
+        V = fa.FunctionSpace(mesh, Ph)
+        k = mesh.num_cells
+        models.append(fa.LinearSpectralExplicit(mesh, fa.tag_box_boundary(mesh), Ph, np.full(k, 1500.0),
+                                                np.full(k, 1000.0), F0, P0, S0, 4, dt, V=V, ctx=ctxs[r]))
+        assert not models[-1].data.is_affine()
+        offs.append(V.global_offset)
+    fa.group_finish_setup(models)
+    for mdl in models:
+        mdl.init()
+    fa.group_rk4_steps(models, 0.0, dt, nsteps)
+    assert np.abs(u).max() > 0
+    for r, mdl in enumerate(models):
+        k = mdl.data.ndofs
+        assert np.abs(mdl.u_sol().x.array - u[offs[r]:offs[r] + k]).max() < 1e-10 * np.abs(u).max()
+        assert np.abs(mdl.v_n.x.array - v[offs[r]:offs[r] + k]).max() < 1e-10 * np.abs(v).max()
+    for mdl in models:
+        mdl.close()
+    for cx in ctxs:
+        cx.close()

@@ -257,6 +257,32 @@ def test_westervelt_rk4_vs_oracle(orc, ctx):
     model.close(), lm.close()
 
 
+@pytest.mark.parametrize("P", [5, 6, 7])
+def test_westervelt_higher_degrees_vs_oracle(orc, ctx, P):
+    """Westervelt (two operator inputs + nonlinear mass terms) through the single-register-set block
+    kernel of the higher degrees (fp64, streamed geometry)."""
+    L, n = 0.012, (3, 3, 2)
+    pr, c, rho, tags = _linear_setup(orc, ctx, n, P, [L, L, L], perturb=0.1, hetero=True)
+    f0, p0, s0 = 0.5e6, 6.0e6, 1500.0
+    w0 = 2 * np.pi * f0
+    nc = pr.mesh.num_cells
+    delta = np.full(nc, fa.compute_diffusivity_of_sound(w0, 1500.0, 0.2))
+    beta = np.where(c > 2000.0, 6.0, 3.5)
+    dt = 0.5 * (L / n[0]) / (c.max() * P**2)
+    nsteps = 10
+    m, src, absb, src2, lin, att = pr.lossy_model_vectors(c, rho, delta, tags)
+    n1 = -2.0 * beta / rho**2 / c**4
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    orc.westervelt_rk4(3, pr.N, pr.dm, pr.G, pr.detJ, pr.D, lin, att, n1, -n1, m, src, absb, src2, f0, p0, s0,
+                       0.0, nsteps * dt * (1 - 1e-9), dt, u, v)
+    model = fa.WesterveltSpectralExplicit(pr.mesh, tags, P, c, rho, delta, beta, f0, p0, s0, 4, dt, V=pr.V, ctx=ctx)
+    assert not model.data.is_affine()
+    model.init()
+    un, vn, _ = model.rk(0.0, nsteps * dt * (1 - 1e-9))
+    assert np.abs(u).max() > 0 and relmax(un.x.array, u) < TOL_RK and relmax(vn.x.array, v) < TOL_RK
+    model.close()
+
+
 @pytest.mark.parametrize("order", [1, 2, 3])
 def test_lower_rk_orders_vs_oracle(orc, ctx, order):
     # rk_order 1-3 of LinearSpectralExplicit (_linear.py:286-311): forward Euler, Ralston 2 / 3

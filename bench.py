@@ -320,6 +320,7 @@ def main():
         if (os.path.exists(pmc) and n == 64 and P == 4 and args.block_elems is None and args.waves is None
                 and not args.deterministic and not affine):
             traffic = json.load(open(pmc))["k_block_op_fused"]["hbm_bytes_per_launch"]
+        triad = ctx.measure_bandwidth()     # measured streaming bandwidth of this device
         out = {
             "metric": ("DOF-updates/sec (RK4 step) at p=4 hex fp64" if (P == 4 and args.dtype == "f64") else
                        f"DOF-updates/sec (RK4 step) at p={P} hex {args.dtype}") + ("" if args.model == "linear" else f" [{args.model} model]"),
@@ -345,12 +346,18 @@ def main():
                        "lds_bytes_per_block": info["lds_bytes"], "dt": dt},
             "roofline": {"bound": "hbm", "kernel": f"k_block_op<{'double' if args.dtype == 'f64' else 'float'},{P},stiffness,+fused RK4 stage>", "achieved": achieved,
                          "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
+                         # measured streaming bandwidth of this device (nt triad, 3 x 512 MiB) and, where the PMC
+                         # traffic applies, the kernel's real HBM rate against it
+                         "measured_triad_GBps": triad, "frac_of_measured_triad": achieved / triad,
+                         "real_traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
+                         "real_traffic_frac_of_triad": (traffic / (avg_ms * 1e-3) / 1e9 / triad) if (traffic and avg_ms > 0) else None,
                          "traffic_source": "profiles/r01g_pmc_traffic.json (separate rocprofv3 --pmc passes)",
                          "algorithmic_bytes_per_launch": alg_launch, "interior_dofs": n_int, "avg_launch_ms": avg_ms,
                          "launches": k_cnt},
             "step_roofline": {"algorithmic_bytes_per_dof_update": b_general,
                               "achieved_GBps": b_general * value / world / 1e9,
-                              "frac_of_8TBps": b_general * value / world / 8e12},
+                              "frac_of_8TBps": b_general * value / world / 8e12,
+                              "frac_of_measured_triad": b_general * value / world / 1e9 / triad},
             # per-operator-action rate, comparable to the reference's logged stiffness actions
             # (2.0e9 DOF/s on 76 Icelake cores, p=4 fp64); here one action also does the fused stage update
             "operator_action_dofs_per_s": (ndl / (avg_ms * 1e-3)) if avg_ms > 0 else None,

@@ -155,6 +155,7 @@ struct fus_ctx
   bool loopback = false;
   bool overlap_blocks = false;  // launch interface blocks first, overlap the exchange with the rest
   bool external_transport = false;  // the caller exchanges the packed interface values (e.g. GPU-aware MPI)
+  int num_cus = 256;                // hipDeviceProp_t::multiProcessorCount
   // Lossy / Westervelt boundary forms: 0 = the C++ benchmarks (BM7-SC1/forms.py:37-42: absorbing and
   // delta-mass terms on every boundary facet, source doubled, Lossy.hpp:216-220); 1 = the Python
   // package (python/src/fenicsxfus/_lossy.py:107-128, :186-189: those terms on tag 2 only, source
@@ -1515,6 +1516,9 @@ int fus_init(int device, fus_ctx** out)
   HIPCHK(hipSetDevice(device));
   auto* c = new fus_ctx();
   c->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0)
+    c->num_cus = prop.multiProcessorCount;
   HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&c->ev_packed, hipEventDisableTiming));
@@ -2267,6 +2271,43 @@ int fus_model_get_mass(fus_model* m, void* out)
 }
 
 int64_t fus_model_ndofs(fus_model* m) { return m ? m->op->ndofs : 0; }
+
+// Measured streaming bandwidth of this device: triad y = x + a z over three arrays of nbytes each
+// (16-byte accesses, all CUs), best of `reps` launches; GB/s counts 3 * nbytes per launch.
+int fus_measure_bandwidth(fus_ctx* c, int64_t nbytes, int reps, double* gbps)
+{
+  if (!c || !gbps || nbytes < (1 << 20) || reps < 1)
+    return fail(FUS_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(c->device));
+  typedef double D2 __attribute__((ext_vector_type(2)));
+  const int64_t nvec = nbytes / 16;
+  D2 *x = nullptr, *z = nullptr, *y = nullptr;
+  HIPCHK(hipMalloc(&x, nvec * 16));
+  HIPCHK(hipMalloc(&z, nvec * 16));
+  HIPCHK(hipMalloc(&y, nvec * 16));
+  HIPCHK(hipMemsetAsync(x, 0, nvec * 16, c->stream));
+  HIPCHK(hipMemsetAsync(z, 0, nvec * 16, c->stream));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  float best = 1e30f;
+  for (int r = 0; r < reps + 1; ++r)  // first launch is a warm-up
+  {
+    HIPCHK(hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL((k_triad<D2>), dim3(c->num_cus * 8), dim3(256), 0, c->stream, nvec,
+                       static_cast<const D2*>(x), static_cast<const D2*>(z), y, 0.5);
+    HIPCHK(hipEventRecord(e1, c->stream));
+    HIPCHK(hipEventSynchronize(e1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    if (r > 0 && ms < best)
+      best = ms;
+  }
+  (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+  (void)hipFree(x), (void)hipFree(z), (void)hipFree(y);
+  *gbps = 3.0 * (double)(nvec * 16) / (best * 1e-3) / 1e9;
+  return FUS_OK;
+}
 
 int fus_profile_enable(fus_ctx* c, int on)
 {

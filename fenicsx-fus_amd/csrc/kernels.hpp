@@ -1410,6 +1410,36 @@ __global__ void k_reciprocal(int64_t n, const T* __restrict__ m, T* __restrict__
     minv[i] = (m[i] != T(0)) ? T(1) / m[i] : T(0);
 }
 
+// Streaming triad y = x + a z with 16-byte accesses: the measured device bandwidth the roofline
+// fractions are also quoted against (fus_measure_bandwidth).
+template <typename V>  // V = 2 doubles as an ext_vector (a template only so that every unit may include it)
+__global__ void __launch_bounds__(256) k_triad(int64_t nvec, const V* __restrict__ x,
+                                               const V* __restrict__ z, V* __restrict__ y, double a)
+{
+  constexpr int U = 4;  // independent 16-byte loads per array in flight per thread
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + (U - 1) * stride < nvec; i += U * stride)
+  {
+    V xv[U], zv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+      xv[u] = __builtin_nontemporal_load(x + i + u * stride);
+      zv[u] = __builtin_nontemporal_load(z + i + u * stride);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+    {
+      __builtin_nontemporal_store(xv[u] + a * zv[u], y + i + u * stride);
+    }
+  }
+  for (; i < nvec; i += stride)
+  {
+    y[i] = x[i] + a * z[i];
+  }
+}
+
 // halo helpers
 // pack: sendbuf[k] = vec[idx[k]] over the concatenated neighbour lists
 template <typename T>

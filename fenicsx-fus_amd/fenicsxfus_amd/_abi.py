@@ -22,7 +22,7 @@ SYMBOLS = [
     "fus_mass_apply", "fus_op_get_geometry", "fus_op_get_tables", "fus_op_info", "fus_op_is_affine", "fus_facet_diag",
     "fus_op_set_neighbours", "fus_model_create", "fus_model_destroy", "fus_model_set_rk_order", "fus_model_init", "fus_model_rk4",
     "fus_model_rk4_steps", "fus_model_get", "fus_model_set", "fus_model_get_mass", "fus_model_ndofs",
-    "fus_profile_enable", "fus_profile_get", "fus_layout_check", "fus_layout_check_ex", "fus_comm_init_local",
+    "fus_profile_enable", "fus_profile_get", "fus_measure_bandwidth", "fus_layout_check", "fus_layout_check_ex", "fus_comm_init_local",
     "fus_group_finish_setup", "fus_group_rk4_steps", "fus_op_halo_layout", "fus_op_halo_buffers",
     "fus_model_setup_count", "fus_model_setup_pack", "fus_model_setup_unpack", "fus_model_setup_finish",
     "fus_model_stage_begin", "fus_model_stage_end",
@@ -136,6 +136,12 @@ class Context:
 
     def profile_enable(self, on: bool = True):
         check(lib().fus_profile_enable(self.h, C.c_int(int(on))))   # 1: all kernels, 2: block operator only
+
+    def measure_bandwidth(self, nbytes: int = 1 << 29, reps: int = 5) -> float:
+        """Streaming triad bandwidth of the device in GB/s (three arrays of nbytes each)."""
+        g = C.c_double()
+        check(lib().fus_measure_bandwidth(self.h, C.c_int64(nbytes), C.c_int(reps), C.byref(g)))
+        return g.value
 
     def profile_get(self, name: str):
         ms, n = C.c_double(), C.c_int64()

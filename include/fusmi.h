@@ -228,6 +228,9 @@ int fus_model_stage_end(fus_model* model, int stage, double t, double dt);
  * kernels, so timed runs use 2 (bench.py) and take the full breakdown in a separate pass. */
 int fus_profile_enable(fus_ctx* ctx, int on);
 int fus_profile_get(fus_ctx* ctx, const char* name, double* total_ms, int64_t* count);
+/* Measured streaming bandwidth of the device (triad y = x + a z over three arrays of nbytes each,
+ * best of reps launches, GB/s): the number the roofline fractions are also quoted against. */
+int fus_measure_bandwidth(fus_ctx* ctx, int64_t nbytes, int reps, double* gbps);
 
 /* Host-only layout builder (no device needed): runs the block partitioner / DOF renumbering on
  * a dofmap and returns statistics as fus_op_info does; used by the CPU test-suite. */

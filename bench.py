@@ -121,6 +121,11 @@ def torch_exchange(torch, dist, model, rank, loopback=False):
     return exchange
 
 
+GEOM_NAMES = {"stream": "general (G streamed, 6 fp64 per point, B_general)",
+              "affine": "affine (7 fp64 per cell, B_affine)",
+              "trilinear": "trilinear (21 fp64 per cell, J and G recomputed per point, B_affine + 14 s / N^3)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -132,10 +137,11 @@ def main():
     ap.add_argument("--block-elems", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
     ap.add_argument("--deterministic", type=int, default=None, help="1: conflict-free rounds, 0: LDS atomics")
-    ap.add_argument("--geometry", choices=["auto", "stream"], default="stream",
-                    help="stream: per-point G from HBM (reference data path); auto: per-cell factors on affine meshes")
+    ap.add_argument("--geometry", choices=["auto", "stream", "trilinear"], default="stream",
+                    help="stream: per-point G from HBM (reference data path); auto: per-cell factors on affine meshes; "
+                         "trilinear: J and G recomputed per point from 21 numbers per cell (any first-order hexahedra)")
     ap.add_argument("--both-geometries", type=int, default=1,
-                    help="also time the other geometry path and report it under 'other_geometry'")
+                    help="also time the other two geometry paths: 'other_geometry' (affine), 'trilinear_geometry', 'streamed_geometry'")
     ap.add_argument("--halo-loopback", action="store_true",
                     help="diagnostic: time the middle slab of 3 with its RCCL exchange looped back to this GPU "
                          "(exchange overhead rehearsal on one GPU; the solution is not the physical one)")
@@ -184,19 +190,21 @@ def main():
             ctx.set_option("halo_loopback", 1)
             ctx.comm_init(1, 3, fa.Context.unique_id())
         args.both_geometries = 0
+    ids2 = ids3 = [None]
     if world > 1 or launched:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        ids2 = [None]
         if transport == "rccl":
             try:
                 ids = [fa.Context.unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
                 ctx.comm_init(rank, world, ids[0])
-                ids2 = [fa.Context.unique_id() if rank == 0 else None]   # communicator of the secondary run
+                ids2 = [fa.Context.unique_id() if rank == 0 else None]   # communicators of the secondary runs
                 dist.broadcast_object_list(ids2, src=0)
+                ids3 = [fa.Context.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(ids3, src=0)
             except fa.FusError as e:            # the library's own RCCL communicator could not be made
                 print(f"[bench rank {rank}] RCCL transport unavailable ({e}); using torch.distributed P2P", file=sys.stderr)
                 transport = "torch"
@@ -246,7 +254,7 @@ def main():
                 model.rk4_steps(t, dt, n, sync=False)
         model.init()
         info = model.data.info()
-        affine = model.data.is_affine()
+        affine = model.data.geometry_mode()        # "stream" | "affine" | "trilinear"
         advance(0.0, warmup)
         if profile:
             context.profile_enable(2)      # HIP events around the dominant kernel only (see fusmi.h)
@@ -278,17 +286,19 @@ def main():
     elapsed, prof, info, affine, finite = run(ctx, args.steps, args.warmup, not args.no_profile)
     if args.no_profile:
         prof = {"stiffness": (0.0, 0), "stiffness_if": (0.0, 0), "breakdown_ms_per_step": {}}
-    # secondary measurement: the same workload through the other geometry path (the box mesh is
-    # affine: "auto" rebuilds G from 7 numbers per cell instead of streaming 6 per point)
-    other = None
+    # secondary measurements: the same workload through the other geometry paths ("auto": the box
+    # mesh is affine, G rebuilt from 7 numbers per cell; "trilinear": J and G recomputed per point
+    # from 21 numbers per cell, valid for any first-order hexahedral mesh; "stream": 6 per point from HBM)
+    others = []
     if args.both_geometries:
-        ctx2 = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves,
-                          deterministic=args.deterministic, geometry="auto" if args.geometry == "stream" else "stream")
-        if world > 1:
-            ctx2.comm_init(rank, world, ids2[0])
-        e2, _, _, aff2, fin2 = run(ctx2, args.steps, args.warmup, False)
-        other = (e2, aff2, fin2)
-        ctx2.close()
+        for g, ids_k in zip([g for g in ("stream", "auto", "trilinear") if g != args.geometry], (ids2, ids3)):
+            ctx2 = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves,
+                              deterministic=args.deterministic, geometry=g)
+            if world > 1:
+                ctx2.comm_init(rank, world, ids_k[0])
+            e2, _, _, aff2, fin2 = run(ctx2, args.steps, args.warmup, False)
+            others.append((e2, aff2, fin2))
+            ctx2.close()
 
     if rank == 0:
         s = 8 if args.dtype == "f64" else 4
@@ -303,7 +313,7 @@ def main():
         # lossy / Westervelt: one more gathered operator input, Westervelt two more vector reads
         extra_x = {"linear": 0, "lossy": 1, "westervelt": 1}[args.model]
         extra_v = {"linear": 0, "lossy": 0, "westervelt": 2}[args.model]
-        b_stiff = rho_e * (s + 4 + (0 if affine else 6 * s) + extra_x * s) + s
+        b_stiff = rho_e * (s + 4 + (0 if affine != "stream" else 6 * s) + extra_x * s) + s
         b_general = 4 * (b_stiff + (12 + extra_v) * s)
         n_int = info["interior_dofs"]
         alg_launch = b_stiff * ndl + (12 + extra_v) * s * n_int
@@ -318,7 +328,7 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")
         if (os.path.exists(pmc) and n == 64 and P == 4 and args.block_elems is None and args.waves is None
-                and not args.deterministic and not affine):
+                and not args.deterministic and affine == "stream"):
             traffic = json.load(open(pmc))["k_block_op_fused"]["hbm_bytes_per_launch"]
         triad = ctx.measure_bandwidth()     # measured streaming bandwidth of this device
         out = {
@@ -339,7 +349,7 @@ def main():
                                    + ("(BASELINE.json configs[1])" if (n, P, args.dtype) == (64, 4, "f64") else
                                      "(BASELINE.json configs[2])" if (n, P, args.dtype) == (128, 7, "f64") else
                                      "(parity/diagnostic configuration)"), "ndofs_global": int(ndofs_global),
-                       "cells_per_gpu": int(nc), "geometry": "affine (7 fp64 per cell, B_affine)" if affine else "general (G streamed, 6 fp64 per point, B_general)",
+                       "cells_per_gpu": int(nc), "geometry": GEOM_NAMES[affine],
                        "partition": "middle x-slab of 3, exchange looped back (diagnostic)" if args.halo_loopback
                        else f"x-slabs x{world}", "transport": transport if (world > 1 or args.halo_loopback) else "none",
                        "blocks": info["nblocks"],
@@ -364,14 +374,13 @@ def main():
             "kernel_ms_per_step": prof["breakdown_ms_per_step"],
             "finite_nonzero_solution": finite,
         }
-        if other is not None:
-            e2, aff2, fin2 = other
-            b2 = 4 * (rho_e * (s + 4 + (0 if aff2 else 6 * s) + extra_x * s) + s + (12 + extra_v) * s)
+        for e2, aff2, fin2 in others:
+            b2 = 4 * (rho_e * (s + 4 + (0 if aff2 != "stream" else 6 * s) + extra_x * s) + s + (12 + extra_v) * s)
             v2 = ndofs_global * args.steps / e2
-            out["other_geometry"] = {"geometry": "affine (7 fp64 per cell, B_affine)" if aff2 else
-                                     "general (G streamed, B_general)", "value": v2, "unit": "DOF-updates/s",
-                                     "ms_per_step": 1e3 * e2 / args.steps, "algorithmic_bytes_per_dof_update": b2,
-                                     "frac_of_8TBps": b2 * v2 / world / 8e12, "finite_nonzero_solution": fin2}
+            key = {"affine": "other_geometry", "trilinear": "trilinear_geometry", "stream": "streamed_geometry"}[aff2]
+            out[key] = {"geometry": GEOM_NAMES[aff2], "value": v2, "unit": "DOF-updates/s",
+                        "ms_per_step": 1e3 * e2 / args.steps, "algorithmic_bytes_per_dof_update": b2,
+                        "frac_of_8TBps": b2 * v2 / world / 8e12, "finite_nonzero_solution": fin2}
         if not args.no_cpu and args.dtype == "f64" and world == 1:   # CPU leg on rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(P, args.cpu_n, args.cpu_steps)
         os.write(result_fd, (json.dumps(out) + "\n").encode())

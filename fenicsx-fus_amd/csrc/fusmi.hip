@@ -139,7 +139,9 @@ struct fus_ctx
   hipEvent_t ev_packed = nullptr, ev_recv = nullptr;
   int deterministic = 0;  // 1: conflict-free rounds (bitwise reproducible); 0: LDS atomics
   int fields = 1;         // operator inputs per block pass the ops are sized for (2: Lossy)
-  int geometry = 0;       // 0: auto (per-cell factors when every cell is affine), 1: always stream G
+  int geometry = 0;       // 0: auto (affine cells: 7 numbers per cell; other first-order hexahedra: the
+                          // cell's trilinear map, G recomputed per point; else streamed), 1: always
+                          // stream G, 2: as auto without the affine shortcut
   // 0 = auto: 32 elements / 4 waves when G is streamed, 16 / 4 on the affine path (measured best
   // on MI355X at p=4 fp64, profiles/r01_block_sweep.txt)
   int block_elems = 0, waves = 0;
@@ -194,6 +196,7 @@ struct fus_op
   int deterministic = 0;
   int nfields = 1;
   bool affine = false;     // GEOM_AFFINE path in use (d_Gc), streamed G/detJ built only on demand
+  bool trilinear = false;  // GEOM_TRILINEAR path in use (d_Gc holds 21 map coefficients per cell)
   void* d_Gc = nullptr;
   void *d_xg = nullptr, *d_pts = nullptr, *d_wts = nullptr;
   int32_t* d_xdm = nullptr;
@@ -308,6 +311,8 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
   DTab<T, N> Dk;
   for (int i = 0; i < N * N; ++i)
     Dk.d[i] = (T)op->D[i];
+  for (int i = 0; i < N; ++i)
+    Dk.w[i] = (T)op->wts[i], Dk.x[i] = (T)op->nodes[i];
   static bool attr_set = false;  // per instantiation
   if (!attr_set)
   {
@@ -346,6 +351,13 @@ static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, 
     return op->deterministic
                ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_AFFINE>(op, gc, coef, x, bvec, S, b0, nb)
                : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_AFFINE>(op, gc, coef, x, bvec, S, b0, nb);
+  }
+  if (op->trilinear)
+  {
+    const T* gc = static_cast<const T*>(op->d_Gc);
+    return op->deterministic
+               ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_TRILINEAR>(op, gc, coef, x, bvec, S, b0, nb)
+               : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_TRILINEAR>(op, gc, coef, x, bvec, S, b0, nb);
   }
   return op->deterministic
              ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_STREAM>(op, geo, coef, x, bvec, S, b0, nb)
@@ -562,12 +574,13 @@ static int op_setup_device(fus_op* op)
   if (op->lds_bytes > 160 * 1024)
     return fail(FUS_ERR_LIMIT, "block does not fit 160 KB of LDS; lower block_elems");
 
-  // derivative table followed by the 1-D weights (the affine path rebuilds w_q from them)
-  std::vector<T> Dg(N * N + N);
+  // derivative table followed by the 1-D weights and points (the per-cell geometry paths rebuild
+  // w_q / J(q) from them)
+  std::vector<T> Dg(N * N + 2 * N);
   for (int i = 0; i < N * N; ++i)
     Dg[i] = (T)op->D[i];
   for (int i = 0; i < N; ++i)
-    Dg[N * N + i] = (T)op->wts[i];
+    Dg[N * N + i] = (T)op->wts[i], Dg[N * N + N + i] = (T)op->nodes[i];
   T* d_Dg;
   FUSCHK(upload(pool, &d_Dg, Dg, st));
   op->d_Dg = d_Dg;
@@ -587,7 +600,7 @@ static int op_setup_device(fus_op* op)
   // per-cell factors + affinity test (every cell a parallelepiped?)
   T* d_Gc;
   unsigned int* d_err;
-  FUSCHK(dalloc(pool, &d_Gc, (size_t)op->ncells * 7));
+  FUSCHK(dalloc(pool, &d_Gc, (size_t)op->ncells * 21));
   FUSCHK(dalloc(pool, &d_err, 1));
   HIPCHK(hipMemsetAsync(d_err, 0, sizeof(unsigned int), st));
   float rel_err = 1.0f;
@@ -603,8 +616,16 @@ static int op_setup_device(fus_op* op)
   }
   op->d_Gc = d_Gc;
   op->affine = c->geometry == 0 && rel_err <= (sizeof(T) == 8 ? 1e-12f : 1e-6f);
+  op->trilinear = !op->affine && c->geometry != 1 && op->geom_order == 1 && op->tdim == 3;
   if (op->affine)
-    op->lds_bytes = L.lds_bytes(sizeof(T), op->nfields, true);
+    op->lds_bytes = L.lds_bytes(sizeof(T), op->nfields, 7);
+  else if (op->trilinear)
+  {
+    hipLaunchKernelGGL((k_geometry_trilinear<T>), dim3(nblk(op->ncells)), dim3(256), 0, st, op->ncells,
+                       op->d_cell_perm, d_xg, op->d_xdm, d_Gc);
+    HIPCHK(hipGetLastError());
+    op->lds_bytes = L.lds_bytes(sizeof(T), op->nfields, 21);
+  }
   else
     FUSCHK((ensure_stream_geometry<T, P>(op)));
 
@@ -1458,15 +1479,23 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   // set there (kernels.hpp, FUS_PF1) and fits two waves per SIMD, which pays only if two blocks per
   // CU are resident: blocks of at most 80 KB of LDS (20 / 12 / 8 elements at p = 5 / 6 / 7 with one
   // operator input, fewer with two).  +50 / +30 / +35 % over one 32->16-element block per CU.
-  const bool two_per_cu = op->dtype == FUS_F64 && op->tdim == 3 && op->P >= 5 && !affine_mesh
+  // first-order hexahedra that are not all affine: J and G recomputed per point from each cell's
+  // trilinear map (GEOM_TRILINEAR) unless the streamed factors are asked for
+  const bool trilinear_mesh = !affine_mesh && c->geometry != 1 && op->geom_order == 1 && op->tdim == 3;
+  const bool two_per_cu = op->dtype == FUS_F64 && op->tdim == 3 && op->P >= 5 && !affine_mesh && !trilinear_mesh
                           && !op->deterministic && c->block_elems <= 0;
   static const int be_two[8] = {0, 0, 0, 0, 0, 20, 12, 8};
   // affine path: about half the streamed size; at p >= 5 again small enough for two blocks per CU
   // (12 / 12 / 8: +11 / +51 / +49 % over 16, profiles/r01_block_sweep.txt)
   static const int be_aff_hi[8] = {0, 0, 0, 0, 0, 12, 12, 8};
   const int be_affine = (op->tdim == 3 && op->P >= 5) ? be_aff_hi[op->P] : be_stream / 2;
-  const int be0 = c->block_elems > 0 ? c->block_elems
-                                     : (two_per_cu ? be_two[op->P] : (affine_mesh ? be_affine : be_stream));
+  const int gcs = affine_mesh ? 7 : (trilinear_mesh ? 21 : 0);
+  // trilinear path: as the affine one except 8 elements at p = 6 (three 52 KB blocks per CU: +20 %)
+  const int be_tri = (op->tdim == 3 && op->P == 6) ? 8 : be_affine;
+  const int be0 = c->block_elems > 0
+                      ? c->block_elems
+                      : (two_per_cu ? be_two[op->P]
+                                    : (trilinear_mesh ? be_tri : (affine_mesh ? be_affine : be_stream)));
   const size_t lds_cap = two_per_cu ? 80 * 1024 : 160 * 1024;
   int waves = c->waves > 0 ? c->waves : 4;
   if (op->P > 4 && waves > 4)
@@ -1476,7 +1505,7 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   {
     std::string err = build_layout(op->L, op->P, op->ncells, op->ndofs, op->h_dofmap.data(),
                                    cen.data(), be, waves, force_shared, op->tdim);
-    const bool too_big = err.empty() ? op->L.lds_bytes(op->ts, op->nfields) + 64 > lds_cap
+    const bool too_big = err.empty() ? op->L.lds_bytes(op->ts, op->nfields, gcs) + 64 > lds_cap
                                      : err.find("65535") != std::string::npos;
     if (too_big && be > 1)
       continue;
@@ -1572,8 +1601,8 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
     c->deterministic = value != 0;
   else if (!strcmp(key, "geometry"))
   {
-    if (value != 0 && value != 1)
-      return fail(FUS_ERR_ARG, "geometry must be 0 (auto) or 1 (stream)");
+    if (value < 0 || value > 2)
+      return fail(FUS_ERR_ARG, "geometry must be 0 (auto), 1 (stream) or 2 (trilinear)");
     c->geometry = (int)value;
   }
   else if (!strcmp(key, "halo_loopback"))
@@ -1782,6 +1811,7 @@ static void layout_info(const Layout& L, size_t ts, int64_t out[8])
 }
 
 int fus_op_is_affine(fus_op* op) { return (op && op->affine) ? 1 : 0; }
+int fus_op_geometry_mode(fus_op* op) { return !op ? 0 : (op->affine ? 1 : (op->trilinear ? 2 : 0)); }
 
 int fus_op_info(fus_op* op, int64_t out[8])
 {

@@ -82,6 +82,7 @@ template <typename T, int N>
 struct DTab
 {
   T d[N * N];
+  T w[N], x[N];  // 1-D GLL weights and points (kernel argument -> scalar registers)
 };
 
 // values per 16-byte (or 8-byte) geometry load
@@ -129,15 +130,107 @@ __device__ unsigned long long g_fus_trace[65536 * 8];
 #define FUS_STAMP(blk, k)
 #endif
 
+// waves per SIMD the GEOM_TRILINEAR block kernel is compiled for: 4 (128 VGPRs) up to degree 4, 2 above
+#ifndef FUS_TRI_WAVES
+#define FUS_TRI_WAVES(P) ((P) <= 4 ? 4 : 2)
+#endif
 // Geometry source of the block operator
 //   GEOM_STREAM: per-point factors G / detJw streamed from HBM (any trilinear mesh; the reference's
 //                data path, precompute.hpp:101-213)
 //   GEOM_AFFINE: every cell is a parallelepiped (J constant per cell): 6 + 1 numbers per CELL,
 //                G(q) = Gc * w_q and detJw(q) = detc * w_q rebuilt in registers
+//   GEOM_TRILINEAR: any first-order hexahedron: 21 numbers per CELL (the coefficients of the trilinear
+//                map without its constant), J(q) and from it G(q) / detJw(q) recomputed per point
+//                in registers (the formulas of geom.hpp); trades the 6 N^3 streamed numbers per
+//                cell for ~65 flops per point
 enum
 {
   GEOM_STREAM = 0,
-  GEOM_AFFINE = 1
+  GEOM_AFFINE = 1,
+  GEOM_TRILINEAR = 2
+};
+
+// numbers per cell held in LDS by the per-cell geometry modes
+__host__ __device__ constexpr int geom_cell_stride(int geom)
+{
+  return geom == GEOM_AFFINE ? 7 : (geom == GEOM_TRILINEAR ? 21 : 0);
+}
+
+// 1 / x to working precision from the hardware estimate (the per-point G of GEOM_TRILINEAR)
+__device__ __forceinline__ double fast_rcp(double x)
+{
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float fast_rcp(float x)
+{
+  float r = __builtin_amdgcn_rcpf(x);
+  r = __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+  return r;
+}
+
+// Lane-constant part of a trilinear cell's Jacobian for the lane's tensor column (X1, X2) = (pb, pc):
+// with x(X) = c0 + c100 X0 + c010 X1 + c001 X2 + c110 X0 X1 + c101 X0 X2 + c011 X1 X2 + c111 X0 X1 X2
+// the columns of J are  j0 = c100 + c110 X1 + c101 X2 + c111 X1 X2  (independent of X0),
+// j1 = (c010 + c011 X2) + X0 (c110 + c111 X2),  j2 = (c001 + c011 X1) + X0 (c101 + c111 X1).
+// cc: the cell's 21 coefficients [c100 c010 c001 c110 c101 c011 c111][3].
+template <typename T>
+struct TriLane
+{
+  T j0[3], a1[3], d1[3], a2[3], d2[3];
+  __device__ __forceinline__ void init(const T* __restrict__ cc, T pb, T pc)
+  {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+      const T c100 = cc[i], c010 = cc[3 + i], c001 = cc[6 + i], c110 = cc[9 + i], c101 = cc[12 + i],
+              c011 = cc[15 + i], c111 = cc[18 + i];
+      d2[i] = c101 + pb * c111;
+      j0[i] = (c100 + pb * c110) + pc * d2[i];
+      a1[i] = c010 + pc * c011;
+      d1[i] = c110 + pc * c111;
+      a2[i] = c001 + pb * c011;
+    }
+  }
+  // stiffness::transform at X0 = pa without forming G: with r_i = rows of det * J^-1,
+  // G = (w / |det|) R R^T, so  G (f0, f1, f2) = (w / |det|) R (R^T f):  f <- cf * G f
+  __device__ __forceinline__ void transform(T pa, T wcf, T& f0, T& f1, T& f2) const
+  {
+    T j1[3], j2[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+      j1[i] = a1[i] + pa * d1[i];
+      j2[i] = a2[i] + pa * d2[i];
+    }
+    const T r0[3] = {j1[1] * j2[2] - j1[2] * j2[1], j1[2] * j2[0] - j1[0] * j2[2], j1[0] * j2[1] - j1[1] * j2[0]};
+    const T r1[3] = {j2[1] * j0[2] - j2[2] * j0[1], j2[2] * j0[0] - j2[0] * j0[2], j2[0] * j0[1] - j2[1] * j0[0]};
+    const T r2[3] = {j0[1] * j1[2] - j0[2] * j1[1], j0[2] * j1[0] - j0[0] * j1[2], j0[0] * j1[1] - j0[1] * j1[0]};
+    const T det = j0[0] * r0[0] + j0[1] * r0[1] + j0[2] * r0[2];
+    const T sc = wcf * fast_rcp(det < T(0) ? -det : det);
+    T t[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      t[i] = sc * (f0 * r0[i] + f1 * r1[i] + f2 * r2[i]);
+    f0 = r0[0] * t[0] + r0[1] * t[1] + r0[2] * t[2];
+    f1 = r1[0] * t[0] + r1[1] * t[1] + r1[2] * t[2];
+    f2 = r2[0] * t[0] + r2[1] * t[1] + r2[2] * t[2];
+  }
+  __device__ __forceinline__ T detw(T pa, T w) const
+  {
+    T j1[3], j2[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+      j1[i] = a1[i] + pa * d1[i];
+      j2[i] = a2[i] + pa * d2[i];
+    }
+    const T det = j0[0] * (j1[1] * j2[2] - j1[2] * j2[1]) + j0[1] * (j1[2] * j2[0] - j1[0] * j2[2])
+                  + j0[2] * (j1[0] * j2[1] - j1[1] * j2[0]);
+    return (det < T(0) ? -det : det) * w;
+  }
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -272,12 +365,19 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
                                              T* __restrict__ sB, const uint16_t* __restrict__ ldm_l,
                                              const T* __restrict__ cf_l, const T* __restrict__ x2_l,
                                              const T* __restrict__ cf2_l, const T* __restrict__ gc_l,
-                                             const T (&w3)[N], int p, int b, int c)
+                                             const T (&w3)[N], const T* __restrict__ D_l, T wbc, T pb,
+                                             T pc, int p, int b, int c)
 {
   constexpr int N2 = N * N, Nd = N * N * N;
   constexpr int VW = GLoad<T, N>::VW;
+  // GEOM_TRILINEAR keeps the lane's rows / columns of the derivative table in LDS (read where used)
+  // so that the kernel fits four waves per SIMD
+  constexpr bool DLDS = (GEOM == GEOM_TRILINEAR);
   if (in.er < 0)
     return;
+  TriLane<T> tri;
+  if (GEOM == GEOM_TRILINEAR)
+    tri.init(gc_l + in.er * 21, pb, pc);
   int li[N];
 #pragma unroll
   for (int a = 0; a < N; ++a)
@@ -342,8 +442,8 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
       for (int j = 0; j < N; ++j)
       {
-        f1 += Drb[j] * sA[a * N2 + j * N + c];
-        f2 += Drc[j] * sA[a * N2 + b * N + j];
+        f1 += (DLDS ? D_l[b * N + j] : Drb[j]) * sA[a * N2 + j * N + c];
+        f2 += (DLDS ? D_l[c * N + j] : Drc[j]) * sA[a * N2 + b * N + j];
       }
       F1[a] = f1;
       F2[a] = f2;
@@ -352,15 +452,22 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
     for (int a = 0; a < N; ++a)
     {
-      T G6[6];
-#pragma unroll
-      for (int gi = 0; gi < 6; ++gi)
+      if (GEOM == GEOM_TRILINEAR)
       {
-        const int v = gi * N + a;
-        if (GEOM == GEOM_STREAM)
-          G6[gi] = in.g[v / VW][v % VW];
-        else
-          G6[gi] = gc_l[in.er * 7 + gi] * w3[a];   // affine cell: G(q) = Gc w_q
+        tri.transform(Dk.x[a], Dk.w[a] * wbc * cf, F0[a], F1[a], F2[a]);
+        continue;
+      }
+      T G6[6];
+      {
+#pragma unroll
+        for (int gi = 0; gi < 6; ++gi)
+        {
+          const int v = gi * N + a;
+          if (GEOM == GEOM_STREAM)
+            G6[gi] = in.g[v / VW][v % VW];
+          else
+            G6[gi] = gc_l[in.er * 7 + gi] * w3[a];   // affine cell: G(q) = Gc w_q
+        }
       }
       const T w0 = F0[a], w1 = F1[a], w2 = F2[a];
       F0[a] = cf * (G6[0] * w0 + G6[1] * w1 + G6[2] * w2);
@@ -383,7 +490,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
         acc += Dk.d[q * N + a] * F0[q];
 #pragma unroll
       for (int j = 0; j < N; ++j)
-        acc += Dcb[j] * sA[a * N2 + j * N + c];
+        acc += (DLDS ? D_l[j * N + b] : Dcb[j]) * sA[a * N2 + j * N + c];
       Y[a] = acc;
     }
     FUS_WAVE_SYNC();
@@ -397,7 +504,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
       T acc = Y[a];
 #pragma unroll
       for (int j = 0; j < N; ++j)
-        acc += Dcc[j] * sA[a * N2 + b * N + j];
+        acc += (DLDS ? D_l[j * N + c] : Dcc[j]) * sA[a * N2 + b * N + j];
       Y[a] = acc;
     }
   }
@@ -406,7 +513,9 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
     // mass::transform (spectral_op.hpp:19-26)
 #pragma unroll
     for (int a = 0; a < N; ++a)
-      Y[a] = cf * x_l[li[a]] * (GEOM == GEOM_STREAM ? in.dj[a] : gc_l[in.er * 7 + 6] * w3[a]);
+      Y[a] = cf * x_l[li[a]]
+             * (GEOM == GEOM_STREAM ? in.dj[a]
+                                    : (GEOM == GEOM_TRILINEAR ? tri.detw(Dk.x[a], Dk.w[a] * wbc) : gc_l[in.er * 7 + 6] * w3[a]));
   }
   // scatter-add into the block accumulator (spectral_op.hpp:240-241); elements of one round
   // share no dof and rounds are ordered -> deterministic
@@ -592,7 +701,7 @@ __device__ __forceinline__ void elem_stiff_bwd(const DTab<T, N>& Dk, const T (&D
 template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3>
 __global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P <= 4 && GEOM == GEOM_AFFINE)
                                                             ? 4
-                                                            : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1))
+                                                            : (GEOM == GEOM_TRILINEAR ? FUS_TRI_WAVES(P) : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1)))
 k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
            const T* __restrict__ geo, const T* __restrict__ coef, const T* __restrict__ x,
            T* __restrict__ bvec, T* __restrict__ partial, const StageArgs<T> S)
@@ -609,9 +718,11 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   T* D_l = scratch + (size_t)A.waves * EPW * Nd;           // derivative table
   T* cf_l = D_l + N2;                                       // per-element coefficient(s)
   T* cf2_l = cf_l + A.lds_nelem;
-  T* gc_l = cf2_l + (NF == 2 ? A.lds_nelem : 0);            // affine cells: 6 G + 1 detJ per element
-  T* w_l = gc_l + (GEOM == GEOM_AFFINE ? 7 * A.lds_nelem : 0);  // 1-D weights (8 slots)
-  uint16_t* ldm_l = reinterpret_cast<uint16_t*>(w_l + (GEOM == GEOM_AFFINE ? 8 : 0));  // 16-B aligned
+  constexpr int GCS = geom_cell_stride(GEOM);               // per-cell geometry numbers (7 / 21 / 0)
+  T* gc_l = cf2_l + (NF == 2 ? A.lds_nelem : 0);            // affine: 6 G + 1 detJ; trilinear: 21 map coefficients
+  T* w_l = gc_l + GCS * A.lds_nelem;                        // 1-D weights (8 slots), 1-D points (8 slots)
+  T* pt_l = w_l + 8;
+  uint16_t* ldm_l = reinterpret_cast<uint16_t*>(w_l + (GCS ? 16 : 0));  // 16-B aligned
   int16_t* rt_l = reinterpret_cast<int16_t*>(ldm_l + (size_t)A.lds_nelem * Nd);
 
   const int blk = blockIdx.x + A.blk_begin;
@@ -666,7 +777,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     const int32_t* gix = A.sh_gidx + sh_off;
     const int n16 = (sh.nelem * Nd * 2 + 15) >> 4;  // ldm_off is a multiple of 8 entries
     const U4* lsrc = reinterpret_cast<const U4*>(A.ldm + sh.ldm_off);
-    const int ngc = (GEOM == GEOM_AFFINE) ? sh.nelem * 7 : 0;
+    const int ngc = sh.nelem * GCS;
 
     // round trip 1
     V2 xi[UI], xi2[UI];
@@ -689,8 +800,8 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
         lq[u] = lsrc[tid + u * nthr];
     const T cfv = (tid < sh.nelem) ? coef[elem_off + tid] : T(0);
     const T cf2v = (NF == 2 && tid < sh.nelem) ? S.coef2[elem_off + tid] : T(0);
-    const T gcv = (tid < ngc) ? geo[(int64_t)elem_off * 7 + tid] : T(0);
-    const T dgv = (tid < N2 + N) ? Dg[tid] : T(0);  // derivative table, then the 1-D weights
+    const T gcv = (tid < ngc) ? geo[(int64_t)elem_off * GCS + tid] : T(0);
+    const T dgv = (tid < N2 + 2 * N) ? Dg[tid] : T(0);  // derivative table, 1-D weights, 1-D points
     const T xtail = (tid == 0 && (sh.nint & 1)) ? x[int_off + sh.nint - 1] : T(0);
     const T xtail2 = (NF == 2 && tid == 0 && (sh.nint & 1)) ? S.x2[int_off + sh.nint - 1] : T(0);
     // round trip 2: the shared dofs' values
@@ -726,8 +837,10 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
       gc_l[tid] = gcv;
     if (tid < N2)
       D_l[tid] = dgv;
-    if (GEOM == GEOM_AFFINE && tid >= N2 && tid < N2 + N)
+    if (GCS && tid >= N2 && tid < N2 + N)
       w_l[tid - N2] = dgv;
+    if (GCS && tid >= N2 + N && tid < N2 + 2 * N)
+      pt_l[tid - N2 - N] = dgv;
     if (tid == 0 && (sh.nint & 1))
     {
       x_l[sh.nint - 1] = xtail;
@@ -810,7 +923,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
         cf2_l[k] = S.coef2[elem_off + k];
     }
     for (int k = tid + nthr; k < ngc; k += nthr)
-      gc_l[k] = geo[(int64_t)elem_off * 7 + k];
+      gc_l[k] = geo[(int64_t)elem_off * GCS + k];
     // the round table (deterministic mode only) -> LDS, so the per-round element lookup is not a
     // global load that would drain the geometry prefetch queue (vmcnt retires in order)
     if (!ATOMIC)
@@ -828,7 +941,8 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
 #pragma unroll
   for (int j = 0; j < N; ++j)
   {
-    constexpr bool inreg = (OP == OP_STIFFNESS) && !(FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) && P >= 6);
+    constexpr bool inreg = (OP == OP_STIFFNESS) && !(FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) && P >= 6)
+                           && GEOM != GEOM_TRILINEAR;
     Drb[j] = inreg ? D_l[b * N + j] : T(0);
     Drc[j] = inreg ? D_l[c * N + j] : T(0);
     Dcb[j] = inreg ? D_l[j * N + b] : T(0);
@@ -838,6 +952,8 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
 #pragma unroll
   for (int a = 0; a < N; ++a)
     w3[a] = (GEOM == GEOM_AFFINE) ? w_l[a] * w_l[b] * w_l[c] : T(0);
+  const T wbc = (GEOM == GEOM_TRILINEAR) ? w_l[b] * w_l[c] : T(0);
+  const T pb = (GEOM == GEOM_TRILINEAR) ? pt_l[b] : T(0), pc = (GEOM == GEOM_TRILINEAR) ? pt_l[c] : T(0);
 
   // ---- trips, two per iteration: while one register set is consumed the other is in flight ----
 #define FUS_ELEM_COMPUTE(in)                                                                       \
@@ -845,7 +961,8 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   {                                                                                                \
     if constexpr (TD == 3)                                                                         \
       elem_compute<T, N, OP, ATOMIC, NF, GEOM>(in, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB,       \
-                                               ldm_l, cf_l, x2_l, cf2_l, gc_l, w3, p, b, c);       \
+                                               ldm_l, cf_l, x2_l, cf2_l, gc_l, w3, D_l, wbc, pb,   \
+                                               pc, p, b, c);                                       \
     else                                                                                           \
       elem_compute2d<T, N, OP, ATOMIC, NF>(in, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, ldm_l, cf_l,      \
                                            x2_l, cf2_l, p, b, c);                                  \
@@ -1278,6 +1395,36 @@ __global__ void k_geometry_affine(int64_t ncells, const int32_t* __restrict__ ce
   Gc[e * 7 + 6] = dw;
   const float rel = (float)sqrt((double)(err2 / h2));
   atomicMax(affine_err_bits, __float_as_uint(rel));  // non-negative floats order like their bits
+}
+
+// First-order hexahedra, GEOM_TRILINEAR: Cc[e][7][3] = coefficients (c100 c010 c001 c110 c101 c011 c111)
+// of the cell's trilinear map x(X) (vertex v = vx + 2 vy + 4 vz), formed as differences of edge
+// vectors so that each keeps the relative accuracy of the edge lengths.
+template <typename T>
+__global__ void k_geometry_trilinear(int64_t ncells, const int32_t* __restrict__ cell_perm,
+                                     const T* __restrict__ xg, const int32_t* __restrict__ xdofmap,
+                                     T* __restrict__ Cc)
+{
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= ncells)
+    return;
+  const int64_t cell = cell_perm[e];
+  for (int i = 0; i < 3; ++i)
+  {
+    T x[8];
+    for (int v = 0; v < 8; ++v)
+      x[v] = xg[3 * (int64_t)xdofmap[cell * 8 + v] + i];
+    const T e10 = x[1] - x[0], e32 = x[3] - x[2], e54 = x[5] - x[4], e76 = x[7] - x[6];
+    const T e20 = x[2] - x[0], e64 = x[6] - x[4];
+    T* o = Cc + e * 21 + i;
+    o[0] = e10;
+    o[3] = e20;
+    o[6] = x[4] - x[0];
+    o[9] = e32 - e10;
+    o[12] = e54 - e10;
+    o[15] = e64 - e20;
+    o[18] = (e76 - e54) - (e32 - e10);
+  }
 }
 
 // Quadrilateral cells: G[e][3][N^2] (xx, xy, yy planes) and detJw[e][N^2] for internal element e

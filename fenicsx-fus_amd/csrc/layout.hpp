@@ -60,13 +60,13 @@ struct Layout
   int32_t max_nloc = 0, max_rounds = 0, max_nelem = 0;
 
   // nfields: operator inputs staged per block (1: Linear; 2: Lossy, K(c1) u + K(c2) v in one pass)
-  size_t lds_bytes(size_t sizeofT, int nfields = 1, bool affine = false) const
+  size_t lds_bytes(size_t sizeofT, int nfields = 1, int geom_cell_stride = 0) const
   {
     const size_t ne = ((size_t)max_nelem + 7) & ~(size_t)7;
     return (size_t)(1 + nfields) * ((max_nloc + 1) & ~1) * sizeofT   // x_l (, x2_l), y_l
            + (size_t)slots * Nd * sizeofT                // per-element exchange tile
            + (size_t)N * N * sizeofT + nfields * ne * sizeofT  // derivative table, coefficients
-           + (affine ? (7 * ne + 8) * sizeofT : 0)             // per-cell geometry, 1-D weights
+           + (geom_cell_stride ? ((size_t)geom_cell_stride * ne + 16) * sizeofT : 0)  // per-cell geometry, 1-D weights + points
            + ne * Nd * 2                                 // local dofmaps
            + (size_t)max_rounds * slots * 2 + 16;        // round table
   }

@@ -104,6 +104,9 @@ class SpectralOperatorData:
     def is_affine(self) -> bool:
         return bool(lib().fus_op_is_affine(self.h))
 
+    def geometry_mode(self) -> str:
+        return ("stream", "affine", "trilinear")[lib().fus_op_geometry_mode(self.h)]
+
     def facet_diag(self, cells, local_facets, cellcoef):
         cells = np.ascontiguousarray(cells, dtype=np.int32)
         lf = np.ascontiguousarray(local_facets, dtype=np.int32)

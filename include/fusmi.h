@@ -51,8 +51,11 @@ int fus_synchronize(fus_ctx* ctx);
 /* Tunables, set before fus_op_create: "block_elems" (elements per LDS block) and "waves"
  * (waves per workgroup, 1..8): default 0 = auto (hexahedra with G streamed: 128 / 64 / 32 /
  * 20 / 12 / 8 elements at P = 2..7 in fp64, 128 / 64 / 48 / 24 / 24 / 16 in fp32, about half of
- * that on the affine path; 4 waves), "geometry" (0 auto |
- * 1 always stream the per-point factors), "fields" (1 | 2: operator inputs the block kernel
+ * that on the affine path; 4 waves), "geometry" (0 auto: 7 numbers
+ * per cell when every cell is a parallelepiped, else -- first-order hexahedra -- the 21 coefficients
+ * of each cell's trilinear map with J and G recomputed per point in the kernel, else the streamed
+ * per-point factors | 1 always stream the per-point factors, the reference's data path | 2 as auto
+ * without the affine shortcut), "fields" (1 | 2: operator inputs the block kernel
  * stages per pass; 2 is required by FUS_LOSSY), "deterministic" (1: elements accumulate in
  * conflict-free rounds, results bitwise reproducible; 0 (default): LDS floating-point atomics, the
  * order of the <= 8 adds per DOF inside a block is free).
@@ -131,9 +134,14 @@ int fus_op_get_tables(fus_op* op, double* weights, double* dphi);
  * out[7]=padded internal vector length. */
 int fus_op_info(fus_op* op, int64_t out[8]);
 /* 1 when every cell was found to be a parallelepiped and the operator rebuilds G = Gc w_q from 7
- * numbers per cell instead of streaming 6 per point (option "geometry" = 0, the default); 0 when
- * the per-point factors are streamed (general trilinear meshes, or option "geometry" = 1). */
+ * numbers per cell instead of streaming 6 per point (option "geometry" = 0, the default); 0
+ * otherwise (see fus_op_geometry_mode). */
 int fus_op_is_affine(fus_op* op);
+/* Geometry source of the block operator: 0 = per-point factors streamed from HBM (the reference's
+ * data path, precompute.hpp:101-213), 1 = affine cells (7 numbers per cell), 2 = first-order
+ * hexahedra with the Jacobian recomputed per point from the cell's trilinear map (21 numbers per
+ * cell; the default for first-order meshes with non-affine cells). */
+int fus_op_geometry_mode(fus_op* op);
 
 /* out[dof] += cellcoef[cell] * |J_facet| w_a w_b at the GLL nodes of each listed boundary facet,
  * facets given as (cell, local facet) pairs in DOLFINx numbering (hex: 0:z=0 1:y=0 2:x=0 3:x=1

@@ -14,9 +14,12 @@ TOL_OP = 1e-12
 TOL_RK = 1e-10
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    c = fa.Context(0)
+# every test taking `ctx` runs through the streamed per-point factors (the reference's data path) and
+# through the default selection (affine cells: 7 numbers per cell; distorted first-order cells: the
+# cell's trilinear map, G recomputed per point)
+@pytest.fixture(scope="module", params=["stream", "auto"])
+def ctx(request):
+    c = fa.Context(0, geometry=request.param)
     yield c
 
 
@@ -53,12 +56,13 @@ def test_stiffness_and_mass_vs_oracle(orc, ctx, P, perturb):
     d.close()
 
 
+@pytest.mark.parametrize("geometry", ["stream", "trilinear"])
 @pytest.mark.parametrize("det", [0, 1])
 @pytest.mark.parametrize("be,w", [(16, 1), (16, 2), (7, 4), (64, 4), (200, 4)])
-def test_block_shapes_and_waves(orc, be, w, det):
+def test_block_shapes_and_waves(orc, be, w, det, geometry):
     # ragged blocks / single-wave workgroups / one block for the whole mesh, both accumulation modes
     pr = Problem(orc, (5, 4, 3), 4, perturb=0.1)
-    c = fa.Context(0, block_elems=be, waves=w, deterministic=bool(det))
+    c = fa.Context(0, block_elems=be, waves=w, deterministic=bool(det), geometry=geometry)
     d = fa.SpectralOperatorData(pr.V, c)
     x = np.random.default_rng(0).standard_normal(pr.ndofs)
     coef = np.full(pr.mesh.num_cells, -1.0 / 3)
@@ -88,7 +92,7 @@ def test_reference_operator_test_recipe(orc, ctx):
 def test_affine_geometry_path(orc, P):
     """Affine meshes (every cell a parallelepiped) take the per-cell geometry path (7 numbers per cell,
     G(q) = Gc w_q); it must agree with the streamed per-point path and with the oracle, and a
-    perturbed mesh must fall back to streaming."""
+    perturbed mesh must leave it (for the cells' trilinear maps)."""
     n = (5, 4, 3) if P <= 4 else (3, 2, 2)
     pr = Problem(orc, n, P, hi=[1.5, 1.0, 0.8])
     rng = np.random.default_rng(P)
@@ -105,7 +109,7 @@ def test_affine_geometry_path(orc, P):
     assert relmax(G, pr.G) < 1e-13 and relmax(dJ, pr.detJ) < 1e-13
     pp = Problem(orc, n, P, hi=[1.5, 1.0, 0.8], perturb=0.1)
     dp = fa.SpectralOperatorData(pp.V, ca)
-    assert not dp.is_affine()
+    assert not dp.is_affine() and dp.geometry_mode() == "trilinear"
     assert relmax(dp.stiffness(x, coef, np.zeros(pr.ndofs)), pp.K(x, coef)) < TOL_OP
     for d in (da, ds, dp):
         d.close()
@@ -350,7 +354,10 @@ def test_full_size_properties(orc, ctx):
     mm = d.mass(np.ones(n), np.full(nc, 1.0), np.zeros(n))
     assert abs(mm.sum() - L**3) < 1e-12 * L**3
     info = d.info()
-    assert d.is_affine() and info["nblocks"] == 262144 // 16 and info["shapes"] == 27   # affine default: 16-element blocks
+    if d.geometry_mode() == "affine":      # affine default: 16-element blocks
+        assert info["nblocks"] == 262144 // 16 and info["shapes"] == 27
+    else:                                  # streamed factors: 32-element blocks
+        assert d.geometry_mode() == "stream" and info["nblocks"] == 262144 // 32
     d.close()
 
 

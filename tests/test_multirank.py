@@ -135,10 +135,11 @@ def test_two_ranks_gloo_cpu(orc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("geometry", ["stream", None])   # streamed G / default (G recomputed from the cell maps)
 @pytest.mark.parametrize("size", [2, 3])
-def test_slabs_in_process_gpu(orc, size):
+def test_slabs_in_process_gpu(orc, size, geometry):
     ref, m_ref, u_ref, v_ref = single_rank_reference(orc)
-    ctxs = [fa.Context(0) for _ in range(size)]
+    ctxs = [fa.Context(0, geometry=geometry) for _ in range(size)]
     fa.Context.init_local_group(ctxs)
     models, offs = [], []
     dt = dt_value()

@@ -323,12 +323,14 @@ def main():
         achieved = alg_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         value = (ndl if args.halo_loopback else ndofs_global) * args.steps / elapsed
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
-        # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01g_pmc_traffic.json, tools/gpu_profile.sh); only quoted
+        # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01i*_pmc_traffic.json, tools/gpu_profile.sh); only quoted
         # for the configuration those passes were taken on
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01g_pmc_traffic.json")
+        pmc_name = {"stream": "r01i_pmc_traffic.json", "trilinear": "r01i_tri_pmc_traffic.json"}.get(affine, "none")
+        pmc = os.path.join(ROOT, "profiles", pmc_name)
         if (os.path.exists(pmc) and n == 64 and P == 4 and args.block_elems is None and args.waves is None
-                and not args.deterministic and affine == "stream"):
+                and not args.deterministic and args.dtype == "f64" and args.model == "linear" and world == 1
+                and not args.halo_loopback):
             traffic = json.load(open(pmc))["k_block_op_fused"]["hbm_bytes_per_launch"]
         triad = ctx.measure_bandwidth()     # measured streaming bandwidth of this device
         out = {
@@ -361,7 +363,7 @@ def main():
                          "measured_triad_GBps": triad, "frac_of_measured_triad": achieved / triad,
                          "real_traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
                          "real_traffic_frac_of_triad": (traffic / (avg_ms * 1e-3) / 1e9 / triad) if (traffic and avg_ms > 0) else None,
-                         "traffic_source": "profiles/r01g_pmc_traffic.json (separate rocprofv3 --pmc passes)",
+                         "traffic_source": f"profiles/{pmc_name} (separate rocprofv3 --pmc passes)" if traffic else None,
                          "algorithmic_bytes_per_launch": alg_launch, "interior_dofs": n_int, "avg_launch_ms": avg_ms,
                          "launches": k_cnt},
             "step_roofline": {"algorithmic_bytes_per_dof_update": b_general,

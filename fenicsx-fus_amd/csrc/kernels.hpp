@@ -801,6 +801,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     const T cfv = (tid < sh.nelem) ? coef[elem_off + tid] : T(0);
     const T cf2v = (NF == 2 && tid < sh.nelem) ? S.coef2[elem_off + tid] : T(0);
     const T gcv = (tid < ngc) ? geo[(int64_t)elem_off * GCS + tid] : T(0);
+    const T gcv2 = (GCS > 7 && tid + nthr < ngc) ? geo[(int64_t)elem_off * GCS + tid + nthr] : T(0);
     const T dgv = (tid < N2 + 2 * N) ? Dg[tid] : T(0);  // derivative table, 1-D weights, 1-D points
     const T xtail = (tid == 0 && (sh.nint & 1)) ? x[int_off + sh.nint - 1] : T(0);
     const T xtail2 = (NF == 2 && tid == 0 && (sh.nint & 1)) ? S.x2[int_off + sh.nint - 1] : T(0);
@@ -835,6 +836,8 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     }
     if (tid < ngc)
       gc_l[tid] = gcv;
+    if (GCS > 7 && tid + nthr < ngc)
+      gc_l[tid + nthr] = gcv2;
     if (tid < N2)
       D_l[tid] = dgv;
     if (GCS && tid >= N2 && tid < N2 + N)
@@ -922,7 +925,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
       if (NF == 2)
         cf2_l[k] = S.coef2[elem_off + k];
     }
-    for (int k = tid + nthr; k < ngc; k += nthr)
+    for (int k = tid + (GCS > 7 ? 2 : 1) * nthr; k < ngc; k += nthr)
       gc_l[k] = geo[(int64_t)elem_off * GCS + k];
     // the round table (deterministic mode only) -> LDS, so the per-round element lookup is not a
     // global load that would drain the geometry prefetch queue (vmcnt retires in order)

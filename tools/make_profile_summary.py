@@ -10,6 +10,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
+extra = sys.argv[2] if len(sys.argv) > 2 else ""
 root = os.path.join("gpurun_out", f"prof_{tag}")
 dst = os.path.join(root, "summary")
 os.makedirs(dst, exist_ok=True)
@@ -44,9 +45,10 @@ rd = sum(per[k]["FETCH_SIZE_per_dispatch"] * per[k]["dispatches"] for k in fused
 wr = sum(per[k]["WRITE_SIZE_per_dispatch"] * per[k]["dispatches"] for k in fused) / max(n, 1) * 1024
 out = {
     "command": "rocprofv3 --pmc <FETCH_SIZE | WRITE_SIZE> --kernel-trace -- python3 bench.py --no-cpu --steps 4 --warmup 1 "
-               "--both-geometries 0 (separate passes; tools/gpu_profile.sh)",
+               "--both-geometries 0 " + extra + " (separate passes; tools/gpu_profile.sh)",
     "tag": tag,
-    "config": "64^3 hex p=4 fp64, general geometry (G streamed), default blocks, LDS atomics, fused RK4 stage epilogue",
+    "config": "64^3 hex p=4 fp64, " + ("geometry per bench args: " + extra if extra else "general geometry (G streamed)")
+              + ", default blocks, LDS atomics, fused RK4 stage epilogue",
     "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request -> x2 (MI355X_MICROARCH.md, HBM); units KiB",
     "k_block_op_fused": {"kernels": fused, "launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
                          "hbm_bytes_per_launch": rd + wr},

@@ -141,7 +141,8 @@ def main():
                     help="stream: per-point G from HBM (reference data path); auto: per-cell factors on affine meshes; "
                          "trilinear: J and G recomputed per point from 21 numbers per cell (any first-order hexahedra)")
     ap.add_argument("--both-geometries", type=int, default=1,
-                    help="also time the other two geometry paths: 'other_geometry' (affine), 'trilinear_geometry', 'streamed_geometry'")
+                    help="1: at N=1 also time the other two geometry paths -> 'other_geometry' (affine), 'trilinear_geometry', "
+                         "'streamed_geometry'; 2: at every N; 0: never")
     ap.add_argument("--halo-loopback", action="store_true",
                     help="diagnostic: time the middle slab of 3 with its RCCL exchange looped back to this GPU "
                          "(exchange overhead rehearsal on one GPU; the solution is not the physical one)")
@@ -290,7 +291,8 @@ def main():
     # mesh is affine, G rebuilt from 7 numbers per cell; "trilinear": J and G recomputed per point
     # from 21 numbers per cell, valid for any first-order hexahedral mesh; "stream": 6 per point from HBM)
     others = []
-    if args.both_geometries:
+    # (one GPU only unless --both-geometries 2: the scaling runs need nothing but the headline line)
+    if args.both_geometries and (world == 1 or args.both_geometries >= 2):
         for g, ids_k in zip([g for g in ("stream", "auto", "trilinear") if g != args.geometry], (ids2, ids3)):
             ctx2 = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves,
                               deterministic=args.deterministic, geometry=g)

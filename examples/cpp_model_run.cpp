@@ -3,6 +3,7 @@
 // (cpp/fenicsx-sf/benchmarks/PH1/BM7-SC1/main.cpp:121-130: construct, init(), rk4(), u_sol()).
 // Mesh and coefficients come from a flat binary file (written by tests/test_cpp_host.py); results
 // go to another.  Usage: cpp_model_run <in.bin> <out.bin>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -88,6 +89,11 @@ int run(Reader& r, const std::vector<int64_t>& h, const std::vector<double>& s, 
   fwrite(ys.data(), 8, ndofs, o), fwrite(ym.data(), 8, ndofs, o), fwrite(u.data(), 8, ndofs, o),
       fwrite(v.data(), 8, ndofs, o), fwrite(tail, 8, 2, o);
   fclose(o);
+  // what the examples' mains print around the run: global smallest cell size (mesh::h + MPI_MIN,
+  // linear_planewave2d_1/main.cpp:60-68) and the L2 norm of the solution (:151-157)
+  const double hmin = ctx->allreduce(data->hmin(), FUS_MIN);
+  const double l2 = std::sqrt(ctx->allreduce(data->norm2(u.data()), FUS_SUM));
+  printf("hmin %.17g L2 norm %.17g\n", hmin, l2);
   printf("ok: %lld steps, %lld dofs\n", (long long)taken, (long long)nd);
   return 0;
 }

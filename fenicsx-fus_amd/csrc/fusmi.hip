@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <limits>
 
 #include <algorithm>
 #include <cmath>
@@ -79,6 +80,7 @@ struct RcclApi
   ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 #ifdef FUS_TU_DEGREE
@@ -114,6 +116,7 @@ static int rccl_load()
   FUS_SYM(Recv, "ncclRecv")
   FUS_SYM(GroupStart, "ncclGroupStart")
   FUS_SYM(GroupEnd, "ncclGroupEnd")
+  FUS_SYM(AllReduce, "ncclAllReduce")
   FUS_SYM(GetErrorString, "ncclGetErrorString")
 #undef FUS_SYM
   g_rccl = a;
@@ -1706,6 +1709,72 @@ int fus_comm_selftest(fus_ctx* c, int64_t n)
   return FUS_OK;
 }
 
+// Scalars every rank needs: the global minimum cell size behind the time step
+// (MPI_Reduce(MIN) + MPI_Bcast, fenicsx-sf-naive/examples/linear_planewave2d_1/main.cpp:67-68) and the
+// sums behind norms (fem::assemble_scalar + MPI sum, :151-157), over the library's RCCL communicator.
+int fus_comm_allreduce(fus_ctx* c, double* values, int n, int op)
+{
+  if (!c || !values || n < 1 || op < FUS_SUM || op > FUS_MAX)
+    return fail(FUS_ERR_ARG, "bad argument");
+  if (c->nranks <= 1 || c->loopback)
+    return FUS_OK;
+  if (c->local_group || !c->comm)
+    return fail(FUS_ERR_STATE, "fus_comm_allreduce needs the RCCL communicator (in-process groups and the "
+                               "external transport reduce on the caller's side)");
+  HIPCHK(hipSetDevice(c->device));
+  double* d = nullptr;
+  HIPCHK(hipMalloc((void**)&d, n * sizeof(double)));
+  HIPCHK(hipMemcpyAsync(d, values, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+  const ncclRedOp_t rop = op == FUS_SUM ? ncclSum : (op == FUS_MIN ? ncclMin : ncclMax);
+  ncclResult_t r = g_rccl.AllReduce(d, d, (size_t)n, ncclDouble, rop, c->comm, c->stream);
+  if (r == ncclSuccess)
+  {
+    HIPCHK(hipMemcpyAsync(values, d, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+  }
+  (void)hipFree(d);
+  NCCLCHK(r);
+  return FUS_OK;
+}
+
+// Smallest cell size of the local mesh, size = largest vertex-to-vertex distance of a cell
+// (dolfinx::mesh::h as used by linear_planewave2d_1/main.cpp:60-64).
+int fus_op_hmin(fus_op* op, double* hmin)
+{
+  if (!op || !hmin)
+    return fail(FUS_ERR_ARG, "null argument");
+  const int nv1 = op->tdim == 3 ? 8 : 4;
+  const int nvg = op->geom_order == 1 ? nv1 : (op->tdim == 3 ? 27 : 9);
+  int vert[8];
+  for (int v = 0; v < nv1; ++v)  // second order: tensor nodes with every index in {0, 2}
+    vert[v] = op->geom_order == 1 ? v : 2 * (v & 1) + 6 * ((v >> 1) & 1) + 18 * (v >> 2);
+  auto coord = [&](int64_t node, int j) -> double
+  {
+    const size_t k = 3 * (size_t)node + j;
+    return op->dtype == FUS_F64 ? reinterpret_cast<const double*>(op->h_geom_x.data())[k]
+                                : (double)reinterpret_cast<const float*>(op->h_geom_x.data())[k];
+  };
+  double best = std::numeric_limits<double>::infinity();
+  for (int64_t cidx = 0; cidx < op->ncells; ++cidx)
+  {
+    double h2 = 0;
+    for (int a = 0; a < nv1; ++a)
+      for (int b = a + 1; b < nv1; ++b)
+      {
+        double d2 = 0;
+        for (int j = 0; j < 3; ++j)
+        {
+          const double d = coord(op->h_geom_dm[cidx * nvg + vert[a]], j) - coord(op->h_geom_dm[cidx * nvg + vert[b]], j);
+          d2 += d * d;
+        }
+        h2 = std::max(h2, d2);
+      }
+    best = std::min(best, h2);
+  }
+  *hmin = std::sqrt(best);
+  return FUS_OK;
+}
+
 int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_t ndofs,
                   const int32_t* tensor_dofmap, const double* nodes1d, const void* geom_x,
                   int64_t nnodes, const int32_t* geom_dofmap, int geom_order, fus_op** out)
@@ -1783,6 +1852,36 @@ int fus_mass_apply(fus_op* op, const void* x, const void* coeffs, void* y, int s
   return d_op_apply(op, OP_MASS, x, coeffs, y, space);
 }
 
+// sum over the LOCAL cells of the GLL-quadrature integral of x^2 (= x . M(1) x with the local,
+// un-exchanged mass action): summed over ranks (fus_comm_allreduce, FUS_SUM) it is the squared L2
+// norm the examples print (fem::assemble_scalar of u*u*dx, linear_planewave2d_1/main.cpp:151-157).
+int fus_op_norm2(fus_op* op, const void* x, int space, double* out)
+{
+  if (!op || !x || !out)
+    return fail(FUS_ERR_ARG, "null argument");
+  const size_t ts = op->ts;
+  std::vector<char> xh(op->ndofs * ts), yh(op->ndofs * ts, 0), ones(op->ncells * ts);
+  if (space == FUS_HOST)
+    memcpy(xh.data(), x, xh.size());
+  else
+  {
+    HIPCHK(hipSetDevice(op->ctx->device));
+    HIPCHK(hipMemcpy(xh.data(), x, xh.size(), hipMemcpyDeviceToHost));
+  }
+  for (int64_t i = 0; i < op->ncells; ++i)
+    if (ts == 8)
+      reinterpret_cast<double*>(ones.data())[i] = 1.0;
+    else
+      reinterpret_cast<float*>(ones.data())[i] = 1.0f;
+  FUSCHK(fus_mass_apply(op, xh.data(), ones.data(), yh.data(), FUS_HOST));
+  long double acc = 0;
+  for (int64_t i = 0; i < op->ndofs; ++i)
+    acc += ts == 8 ? (long double)reinterpret_cast<double*>(xh.data())[i] * reinterpret_cast<double*>(yh.data())[i]
+                   : (long double)reinterpret_cast<float*>(xh.data())[i] * reinterpret_cast<float*>(yh.data())[i];
+  *out = (double)acc;
+  return FUS_OK;
+}
+
 int fus_op_get_geometry(fus_op* op, void* G, void* detJ)
 {
   if (!op)
@@ -1818,6 +1917,7 @@ int fus_op_info(fus_op* op, int64_t out[8])
   if (!op || !out)
     return fail(FUS_ERR_ARG, "null argument");
   layout_info(op->L, op->ts, out);
+  out[6] = (int64_t)op->lds_bytes;  // what the block kernel is launched with (fields, geometry mode)
   return FUS_OK;
 }
 

@@ -101,6 +101,21 @@ class SpectralOperatorData:
                 "internal_len"]
         return dict(zip(keys, list(out)))
 
+    def hmin(self) -> float:
+        """Smallest local cell size (largest vertex distance per cell, dolfinx mesh::h; main.cpp:60-64)."""
+        out = C.c_double()
+        check(lib().fus_op_hmin(self.h, C.byref(out)))
+        return out.value
+
+    def norm2(self, x) -> float:
+        """Local part of the squared L2 norm, sum over the local cells of the GLL integral of x^2
+        (assemble_scalar(u*u*dx), main.cpp:151-157); sum it over the ranks."""
+        x = np.ascontiguousarray(_array(x), dtype=self.dtype)
+        assert x.shape[0] == self.ndofs
+        out = C.c_double()
+        check(lib().fus_op_norm2(self.h, ptr(x), C.c_int(_abi.FUS_HOST), C.byref(out)))
+        return out.value
+
     def is_affine(self) -> bool:
         return bool(lib().fus_op_is_affine(self.h))
 

@@ -80,6 +80,15 @@ int fus_comm_init(fus_ctx* ctx, int rank, int nranks, const void* id128);
  * (checks the run-time RCCL binding; RCCL is dlopen'ed, preferring a copy already resident in the
  * process such as PyTorch's, or $FUSMI_RCCL). */
 int fus_comm_selftest(fus_ctx* ctx, int64_t n);
+/* In-place all-reduce of n host doubles over the ranks of fus_comm_init (RCCL): the global minimum
+ * cell size behind the time step (MPI_Reduce(MIN) + MPI_Bcast,
+ * cpp/fenicsx-sf-naive/examples/linear_planewave2d_1/main.cpp:67-68) and the sums behind norms
+ * (:151-157).  One rank: no-op.  In-process groups / external transport: FUS_ERR_STATE (the caller
+ * holds every rank's value, or its own transport). */
+#define FUS_SUM 0
+#define FUS_MIN 1
+#define FUS_MAX 2
+int fus_comm_allreduce(fus_ctx* ctx, double* values, int n, int op);
 
 /* In-process transport for rehearsing the multi-rank path on ONE GPU (tests): the n contexts of
  * this process become ranks 0..n-1 and interface planes move by device copies instead of RCCL.
@@ -142,6 +151,13 @@ int fus_op_is_affine(fus_op* op);
  * hexahedra with the Jacobian recomputed per point from the cell's trilinear map (21 numbers per
  * cell; the default for first-order meshes with non-affine cells). */
 int fus_op_geometry_mode(fus_op* op);
+/* Smallest cell size of the local mesh, the size of a cell being its largest vertex-to-vertex
+ * distance (dolfinx::mesh::h, linear_planewave2d_1/main.cpp:60-64); dt = CFL hmin / (c P^2), :102. */
+int fus_op_hmin(fus_op* op, double* hmin);
+/* out = sum over the local cells of the GLL-quadrature integral of x^2 (caller numbering; loc =
+ * FUS_HOST | FUS_DEVICE); the sum over ranks is the squared L2 norm of
+ * fem::assemble_scalar(u*u*dx), linear_planewave2d_1/main.cpp:151-157. */
+int fus_op_norm2(fus_op* op, const void* x, int loc, double* out);
 
 /* out[dof] += cellcoef[cell] * |J_facet| w_a w_b at the GLL nodes of each listed boundary facet,
  * facets given as (cell, local facet) pairs in DOLFINx numbering (hex: 0:z=0 1:y=0 2:x=0 3:x=1

@@ -70,6 +70,12 @@ public:
     return id;
   }
   void comm_init(int rank, int nranks, const std::vector<char>& id) { check(fus_comm_init(h_, rank, nranks, id.data())); }
+  // MPI_Reduce + MPI_Bcast of the examples' mains (linear_planewave2d_1/main.cpp:67-68): op = FUS_SUM | FUS_MIN | FUS_MAX
+  double allreduce(double v, int op)
+  {
+    check(fus_comm_allreduce(h_, &v, 1, op));
+    return v;
+  }
   fus_ctx* handle() const { return h_; }
 
 private:
@@ -133,6 +139,21 @@ public:
   std::int64_t ndofs() const { return ndofs_; }
   int tdim() const { return tdim_; }
   bool is_affine() const { return fus_op_is_affine(h_) != 0; }
+  int geometry_mode() const { return fus_op_geometry_mode(h_); }  // 0 streamed, 1 affine, 2 trilinear
+  // smallest local cell size, mesh::h of linear_planewave2d_1/main.cpp:60-64 (global: Context::allreduce(h, FUS_MIN))
+  double hmin() const
+  {
+    double h = 0;
+    check(fus_op_hmin(h_, &h));
+    return h;
+  }
+  // local part of the squared L2 norm (assemble_scalar(u*u*dx), main.cpp:151-157); sum over ranks
+  double norm2(const T* x, int loc = FUS_HOST) const
+  {
+    double v = 0;
+    check(fus_op_norm2(h_, x, loc, &v));
+    return v;
+  }
 
 private:
   std::shared_ptr<Context> ctx_;

@@ -86,6 +86,12 @@ def test_cpp_host_classes_vs_oracle(orc, exe, tmp_path, kind, n, P):
     rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()  # noqa: E731
     assert rel(ys, 1.0 + pr.K(x, coeffs)) < 1e-12 and rel(ym, 1.0 + pr.M(x, coeffs)) < 1e-14
     tf = nsteps * dt * (1 - 1e-9)
+    # the mesh size and norm the examples' mains report (linear_planewave2d_1/main.cpp:60-68, 151-157)
+    words = out.stdout.split()
+    hmin, l2 = float(words[words.index("hmin") + 1]), float(words[words.index("norm") + 1])
+    X, gdm = pr.mesh.geometry.x, pr.mesh.geometry.dofmap
+    assert abs(hmin - min(max(np.linalg.norm(X[a] - X[b]) for a in cell for b in cell) for cell in gdm)) < 1e-15
+    assert abs(l2 - np.sqrt(u @ pr.M(u))) < 1e-12 * l2
     uo, vo = np.zeros(nd), np.zeros(nd)
     if kind == 0:
         m, src, absb, coeff = pr.linear_model_vectors(c, rho, tags)

@@ -536,3 +536,37 @@ def test_unstructured_numbering_and_holes(orc, ctx):
     un, vn, _ = model.rk(0.0, 12 * dt * (1 - 1e-9))
     assert np.abs(u).max() > 0 and relmax(un.x.array, u) < TOL_RK and relmax(vn.x.array, v) < TOL_RK
     model.close()
+
+
+def test_mesh_size_norm_and_allreduce(orc):
+    """What the examples' mains compute around the model (linear_planewave2d_1/main.cpp:60-68, 102,
+    151-157): smallest cell size (cell size = largest vertex distance), its global minimum, the time
+    step from it, and the L2 norm of the solution."""
+    L, n, P = [1.5, 1.0, 0.8], (6, 5, 4), 4
+    pr = Problem(orc, n, P, hi=L)
+    c = fa.Context(0)
+    d = fa.SpectralOperatorData(pr.V, c)
+    hx = [L[i] / n[i] for i in range(3)]
+    assert abs(d.hmin() - np.sqrt(sum(h * h for h in hx))) < 1e-14
+    assert c.allreduce([d.hmin()], "min")[0] == d.hmin()          # one rank: identity
+    x = np.random.default_rng(0).standard_normal(pr.ndofs)
+    ref = x @ pr.M(x)
+    assert abs(d.norm2(x) - ref) < 1e-13 * ref
+    d.close()
+    # distorted and second-order cells: the vertices of each cell decide
+    pp = Problem(orc, n, P, hi=L, perturb=0.2)
+    dp = fa.SpectralOperatorData(pp.V, c)
+    X, dm = pp.mesh.geometry.x, pp.mesh.geometry.dofmap
+    h = min(max(np.linalg.norm(X[a] - X[b]) for a in cell for b in cell) for cell in dm)
+    assert abs(dp.hmin() - h) < 1e-14
+    assert abs(dp.norm2(x) - x @ pp.M(x)) < 1e-13 * ref
+    dp.close()
+    p2 = Problem(orc, (3, 3, 2), 4, hi=[0.012, 0.012, 0.008], order=2,
+                 warp=lambda y: y + np.c_[20.0 * y[:, 1] ** 2, 15.0 * y[:, 2] ** 2, 0 * y[:, 0]])
+    d2 = fa.SpectralOperatorData(p2.V, c)
+    X, dm = p2.mesh.geometry.x, p2.mesh.geometry.dofmap
+    corners = [0, 2, 6, 8, 18, 20, 24, 26]
+    h = min(max(np.linalg.norm(X[cell[a]] - X[cell[b]]) for a in corners for b in corners) for cell in dm)
+    assert abs(d2.hmin() - h) < 1e-14
+    d2.close()
+    c.close()

@@ -165,6 +165,13 @@ def test_slabs_in_process_gpu(orc, size, geometry):
     for r in range(size - 1):       # interface planes bit-identical on both sharers
         plane = len(us[r]) - (offs[r + 1] - offs[r])
         assert np.array_equal(us[r][-plane:], us[r + 1][:plane])
+    # the ranks' local parts of the squared L2 norm add up to the single-rank integral, and the
+    # global smallest cell size is the minimum of the local ones (main.cpp:60-68, 151-157)
+    w = ref.M(np.ones(ref.ndofs))
+    assert abs(sum(mdl.data.norm2(u) for mdl, u in zip(models, us)) - w @ u_ref**2) < 1e-9 * (w @ u_ref**2)
+    X, dm = ref.mesh.geometry.x, ref.mesh.geometry.dofmap
+    h = min(max(np.linalg.norm(X[a] - X[b]) for a in cell for b in cell) for cell in dm)
+    assert abs(min(mdl.data.hmin() for mdl in models) - h) < 1e-14
     for mdl in models:
         mdl.close()
     for c in ctxs:

@@ -1672,7 +1672,7 @@ int fus_comm_init(fus_ctx* c, int rank, int nranks, const void* id128)
 // checks the run-time RCCL binding and the grouped send/recv pattern the halo exchange uses.
 int fus_comm_selftest(fus_ctx* c, int64_t n)
 {
-  if (!c || n < 1)
+  if (!c || n < 2)
     return fail(FUS_ERR_ARG, "bad argument");
   HIPCHK(hipSetDevice(c->device));
   FUSCHK(rccl_load());
@@ -1699,6 +1699,13 @@ int fus_comm_selftest(fus_ctx* c, int64_t n)
   NCCLCHK(g_rccl.Recv(b, n, ncclDouble, self, comm, c->stream));
   NCCLCHK(g_rccl.GroupEnd());
   HIPCHK(hipMemcpyAsync(back.data(), b, n * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+  // and the all-reduce of fus_comm_allreduce (over this communicator's ranks; a 1-rank one returns its input)
+  double red[2] = {0, 0};
+  if (own || c->nranks == 1)
+  {
+    NCCLCHK(g_rccl.AllReduce(a, a, 2, ncclDouble, ncclMin, comm, c->stream));
+    HIPCHK(hipMemcpyAsync(red, a, sizeof(red), hipMemcpyDeviceToHost, c->stream));
+  }
   HIPCHK(hipStreamSynchronize(c->stream));
   (void)hipFree(a), (void)hipFree(b);
   if (own)
@@ -1706,6 +1713,8 @@ int fus_comm_selftest(fus_ctx* c, int64_t n)
   for (int64_t i = 0; i < n; ++i)
     if (back[i] != h[i])
       return fail(FUS_ERR_RCCL, "RCCL self send/recv returned wrong data");
+  if ((own || c->nranks == 1) && n >= 2 && (red[0] != h[0] || red[1] != h[1]))
+    return fail(FUS_ERR_RCCL, "RCCL all-reduce over one rank changed the data");
   return FUS_OK;
 }
 

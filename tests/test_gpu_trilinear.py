@@ -169,3 +169,22 @@ def test_full_size_agrees_with_streamed_path():
     assert np.abs(res["stream"][0]).max() > 0
     assert relmax(res["trilinear"][0], res["stream"][0]) < 1e-11
     assert relmax(res["trilinear"][1], res["stream"][1]) < 1e-11
+
+
+@pytest.mark.parametrize("geometry", ["stream", "trilinear"])
+def test_mirrored_cells_negative_jacobian(orc, geometry):
+    """A reflected mesh (det J < 0 in every cell): the factors use |det J| (precompute.hpp:84, 201),
+    on both geometry paths."""
+    pr = Problem(orc, (5, 4, 3), 4, hi=[1.5, 1.0, 0.8], perturb=0.2)
+    pr.mesh.geometry.x[:, 0] *= -1.0
+    pr.G, pr.detJ = orc.geometry(3, pr.mesh.geometry.x, pr.mesh.geometry.dofmap, pr.nodes, pr.wts)
+    assert (pr.detJ > 0).all()
+    c = fa.Context(0, geometry=geometry)
+    d = fa.SpectralOperatorData(pr.V, c)
+    assert d.geometry_mode() == geometry
+    rng = np.random.default_rng(3)
+    x, coef = rng.standard_normal(pr.ndofs), rng.uniform(0.5, 2.0, pr.mesh.num_cells)
+    assert relmax(d.stiffness(x, coef, np.zeros(pr.ndofs)), pr.K(x, coef)) < TOL_OP
+    assert relmax(d.mass(x, coef, np.zeros(pr.ndofs)), pr.M(x, coef)) < 1e-13
+    d.close()
+    c.close()

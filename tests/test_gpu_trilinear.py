@@ -82,16 +82,21 @@ def test_second_order_geometry_falls_back_to_stream(orc, ctx):
     d.close()
 
 
-def test_fp32(orc):
-    pr = Problem(orc, (6, 5, 4), 4, perturb=0.2, dtype=np.float32)
-    c = fa.Context(0, geometry="trilinear")
+@pytest.mark.parametrize("P", [2, 3, 4, 5, 6, 7])
+def test_fp32(orc, P):
+    n = (6, 5, 4) if P <= 4 else (3, 3, 2)
+    pr = Problem(orc, n, P, perturb=0.2, dtype=np.float32)
+    c = fa.Context(0)                      # default selection: distorted first-order cells -> trilinear
     rng = np.random.default_rng(2)
     x = rng.standard_normal(pr.ndofs).astype(np.float32)
     d = fa.SpectralOperatorData(pr.V, c)
     assert d.geometry_mode() == "trilinear"
     y = fa.StiffnessSpectral3D(pr.V, d)(x, np.ones(pr.mesh.num_cells, np.float32), np.zeros(pr.ndofs, np.float32))
-    assert y.dtype == np.float32 and relmax(y, pr.K(x)) < 2e-5
+    assert y.dtype == np.float32 and relmax(y, pr.K(x)) < 5e-5
+    ym = fa.MassSpectral3D(pr.V, d)(x, np.ones(pr.mesh.num_cells, np.float32), np.zeros(pr.ndofs, np.float32))
+    assert relmax(ym, pr.M(x)) < 1e-5
     d.close()
+    c.close()
 
 
 def _setup(orc, n, P, L, hetero=True):

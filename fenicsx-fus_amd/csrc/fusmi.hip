@@ -1488,13 +1488,13 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   const bool two_per_cu = op->dtype == FUS_F64 && op->tdim == 3 && op->P >= 5 && !affine_mesh && !trilinear_mesh
                           && !op->deterministic && c->block_elems <= 0;
   static const int be_two[8] = {0, 0, 0, 0, 0, 20, 12, 8};
-  // affine path: about half the streamed size; at p >= 5 again small enough for two blocks per CU
-  // (12 / 12 / 8: +11 / +51 / +49 % over 16, profiles/r01_block_sweep.txt)
-  static const int be_aff_hi[8] = {0, 0, 0, 0, 0, 12, 12, 8};
+  // per-cell geometry paths (affine, trilinear): about half the streamed size; at p >= 5 blocks of 8
+  // elements, small enough for four / three / two blocks per CU at the register budgets of those
+  // kernels (p=5: +3-5 % over 12, p=6: +19-20 %; profiles/r01_block_sweep.txt)
+  static const int be_aff_hi[8] = {0, 0, 0, 0, 0, 8, 8, 8};
   const int be_affine = (op->tdim == 3 && op->P >= 5) ? be_aff_hi[op->P] : be_stream / 2;
   const int gcs = affine_mesh ? 7 : (trilinear_mesh ? 21 : 0);
-  // trilinear path: as the affine one except 8 elements at p = 6 (three 52 KB blocks per CU: +20 %)
-  const int be_tri = (op->tdim == 3 && op->P == 6) ? 8 : be_affine;
+  const int be_tri = be_affine;
   const int be0 = c->block_elems > 0
                       ? c->block_elems
                       : (two_per_cu ? be_two[op->P]

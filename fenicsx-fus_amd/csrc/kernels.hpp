@@ -130,9 +130,10 @@ __device__ unsigned long long g_fus_trace[65536 * 8];
 #define FUS_STAMP(blk, k)
 #endif
 
-// waves per SIMD the GEOM_TRILINEAR block kernel is compiled for: 4 (128 VGPRs) up to degree 4, 2 above
+// waves per SIMD the GEOM_TRILINEAR block kernel is compiled for: 4 (128 VGPRs) up to degree 5, 2 above
+// (degrees 6 / 7 need 161 / 184 VGPRs; capping 7 at 168 measured no gain)
 #ifndef FUS_TRI_WAVES
-#define FUS_TRI_WAVES(P) ((P) <= 4 ? 4 : 2)
+#define FUS_TRI_WAVES(P) ((P) <= 5 ? 4 : 2)
 #endif
 // Geometry source of the block operator
 //   GEOM_STREAM: per-point factors G / detJw streamed from HBM (any trilinear mesh; the reference's
@@ -372,7 +373,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
   constexpr int VW = GLoad<T, N>::VW;
   // GEOM_TRILINEAR keeps the lane's rows / columns of the derivative table in LDS (read where used)
   // so that the kernel fits four waves per SIMD
-  constexpr bool DLDS = (GEOM == GEOM_TRILINEAR);
+  constexpr bool DLDS = (GEOM == GEOM_TRILINEAR) || (GEOM == GEOM_AFFINE && (N == 6 || N == 7));
   if (in.er < 0)
     return;
   TriLane<T> tri;
@@ -695,13 +696,15 @@ __device__ __forceinline__ void elem_stiff_bwd(const DTab<T, N>& Dk, const T (&D
 // are written straight from here.  Shared dofs still leave as partial sums.
 // Launch bound: up to 8 waves per workgroup for P <= 4; the higher degrees are limited to 4 waves and
 // either use the whole 512-entry register file with one wave per SIMD (two geometry register sets:
-// fp32, affine, deterministic variants) or -- FUS_PF1, fp64 streamed geometry -- keep one set and fit
-// two waves per SIMD.
+// fp32 and deterministic streamed variants, affine at degree 7), or -- FUS_PF1, fp64 streamed
+// geometry -- keep one set and fit two waves per SIMD, or -- the per-cell geometry modes, which hold
+// no geometry registers -- are compiled for FUS_TRI_WAVES(P) waves per SIMD with the lane's
+// derivative-table rows read from LDS where used.
 // TD = 2: the same block machinery for quadrilateral elements (Nd = N^2, GEOM_STREAM only).
 template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3>
 __global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P <= 4 && GEOM == GEOM_AFFINE)
                                                             ? 4
-                                                            : (GEOM == GEOM_TRILINEAR ? FUS_TRI_WAVES(P) : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1)))
+                                                            : ((GEOM == GEOM_TRILINEAR || (GEOM == GEOM_AFFINE && P <= 6)) ? FUS_TRI_WAVES(P) : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1)))
 k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
            const T* __restrict__ geo, const T* __restrict__ coef, const T* __restrict__ x,
            T* __restrict__ bvec, T* __restrict__ partial, const StageArgs<T> S)
@@ -945,7 +948,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   for (int j = 0; j < N; ++j)
   {
     constexpr bool inreg = (OP == OP_STIFFNESS) && !(FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) && P >= 6)
-                           && GEOM != GEOM_TRILINEAR;
+                           && GEOM != GEOM_TRILINEAR && !(GEOM == GEOM_AFFINE && (P == 5 || P == 6));
     Drb[j] = inreg ? D_l[b * N + j] : T(0);
     Drc[j] = inreg ? D_l[c * N + j] : T(0);
     Dcb[j] = inreg ? D_l[j * N + b] : T(0);

@@ -51,7 +51,7 @@ int fus_synchronize(fus_ctx* ctx);
 /* Tunables, set before fus_op_create: "block_elems" (elements per LDS block) and "waves"
  * (waves per workgroup, 1..8): default 0 = auto (hexahedra with G streamed: 128 / 64 / 32 /
  * 20 / 12 / 8 elements at P = 2..7 in fp64, 128 / 64 / 48 / 24 / 24 / 16 in fp32, about half of
- * that on the affine path; 4 waves), "geometry" (0 auto: 7 numbers
+ * that -- 8 at P >= 5 -- on the affine and trilinear paths; 4 waves), "geometry" (0 auto: 7 numbers
  * per cell when every cell is a parallelepiped, else -- first-order hexahedra -- the 21 coefficients
  * of each cell's trilinear map with J and G recomputed per point in the kernel, else the streamed
  * per-point factors | 1 always stream the per-point factors, the reference's data path | 2 as auto

@@ -1364,7 +1364,7 @@ __global__ void k_geometry(int64_t ncells, const int32_t* __restrict__ cell_perm
 // Affine cells: Gc[e][0..5] = K K^T |det J| (no quadrature weight), Gc[e][6] = |det J| with the
 // constant Jacobian J = [x1-x0, x2-x0, x4-x0] (same formulas as geometric_factor3 with w = 1).
 // affine_err_bits receives the largest deviation of the other vertices from the parallelepiped,
-// relative to the cell size: the host falls back to GEOM_STREAM when it is not ~0.
+// relative to the cell size: the host leaves the affine path (for GEOM_TRILINEAR, or GEOM_STREAM on request) when it is not ~0.
 template <typename T>
 __global__ void k_geometry_affine(int64_t ncells, const int32_t* __restrict__ cell_perm,
                                   const T* __restrict__ xg, const int32_t* __restrict__ xdofmap,

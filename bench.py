@@ -8,11 +8,17 @@ boundary terms + fused stage update) of the Linear acoustic model on BASELINE.js
 3-D homogeneous water box, 64^3 hexes, p=4, fp64 (16 974 593 DOFs per GPU).  At N>1 each rank owns
 a 64^3 x-slab of a (64 N) x 64 x 64 box (weak scaling) and exchanges one interface plane per
 neighbour per stage over RCCL.  All state is resident in HBM when the timed region starts.
+The headline goes through the library's kernel for general first-order hexahedral meshes (J and G
+recomputed per point from each cell's trilinear map, --geometry trilinear: the synthetic box is not
+allowed its affine shortcut); the reference's data path (per-point G streamed from HBM) and the
+affine path are timed beside it at N=1 ('streamed_geometry', 'other_geometry').
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement) including
   roofline     -- the dominant kernel (block stiffness operator): algorithmic bytes per launch
-                  (SURVEY 8d stiffness term: rho_e (s + 4 + 6 s) + s per DOF) / its average
-                  duration measured with HIP events on the library's stream
+                  (SURVEY 8d stiffness term: rho_e (s + 4 + g) + s per DOF, g = the path's geometry
+                  bytes per element-DOF: 6 s streamed, 21 s / N^3 trilinear, 7 s / N^3 affine; plus
+                  the fused stage update of the interior DOFs) / its average duration measured
+                  with HIP events on the library's stream
   cpu_baseline -- the CPU oracle (port of the reference loop, -Ofast) timed on this host
 """
 import argparse
@@ -121,9 +127,10 @@ def torch_exchange(torch, dist, model, rank, loopback=False):
     return exchange
 
 
-GEOM_NAMES = {"stream": "general (G streamed, 6 fp64 per point, B_general)",
-              "affine": "affine (7 fp64 per cell, B_affine)",
-              "trilinear": "trilinear (21 fp64 per cell, J and G recomputed per point, B_affine + 14 s / N^3)"}
+GEOM_NAMES = {"stream": "general, G streamed (6 values per point from HBM: the reference's data path, B_general)",
+              "affine": "affine cells (7 values per cell, B_affine)",
+              "trilinear": "general first-order hexahedra, trilinear (21 values per cell, J and G recomputed per point, "
+                           "B_affine + 14 s / N^3 per element-DOF)"}
 
 
 def main():
@@ -137,9 +144,11 @@ def main():
     ap.add_argument("--block-elems", type=int, default=None)
     ap.add_argument("--waves", type=int, default=None)
     ap.add_argument("--deterministic", type=int, default=None, help="1: conflict-free rounds, 0: LDS atomics")
-    ap.add_argument("--geometry", choices=["auto", "stream", "trilinear"], default="stream",
-                    help="stream: per-point G from HBM (reference data path); auto: per-cell factors on affine meshes; "
-                         "trilinear: J and G recomputed per point from 21 numbers per cell (any first-order hexahedra)")
+    ap.add_argument("--geometry", choices=["auto", "stream", "trilinear"], default="trilinear",
+                    help="trilinear (headline): J and G recomputed per point from 21 numbers per cell -- what the library "
+                         "does by default on any first-order hexahedral mesh with non-affine cells, taken here without "
+                         "the affine shortcut the synthetic box would allow; stream: per-point G from HBM (the reference's "
+                         "data path); auto: the library default (this box is affine: 7 numbers per cell)")
     ap.add_argument("--both-geometries", type=int, default=1,
                     help="1: at N=1 also time the other two geometry paths -> 'other_geometry' (affine), 'trilinear_geometry', "
                          "'streamed_geometry'; 2: at every N; 0: never")
@@ -315,7 +324,8 @@ def main():
         # lossy / Westervelt: one more gathered operator input, Westervelt two more vector reads
         extra_x = {"linear": 0, "lossy": 1, "westervelt": 1}[args.model]
         extra_v = {"linear": 0, "lossy": 0, "westervelt": 2}[args.model]
-        b_stiff = rho_e * (s + 4 + (0 if affine != "stream" else 6 * s) + extra_x * s) + s
+        geo_b = {"stream": 6 * s, "affine": 7 * s / N3, "trilinear": 21 * s / N3}   # geometry bytes per element-DOF
+        b_stiff = rho_e * (s + 4 + geo_b[affine] + extra_x * s) + s
         b_general = 4 * (b_stiff + (12 + extra_v) * s)
         n_int = info["interior_dofs"]
         alg_launch = b_stiff * ndl + (12 + extra_v) * s * n_int
@@ -325,10 +335,10 @@ def main():
         achieved = alg_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         value = (ndl if args.halo_loopback else ndofs_global) * args.steps / elapsed
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
-        # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01i*_pmc_traffic.json, tools/gpu_profile.sh); only quoted
+        # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01j_pmc_traffic.json (trilinear), r01i_pmc_traffic.json (streamed), tools/gpu_profile.sh); only quoted
         # for the configuration those passes were taken on
         traffic = None
-        pmc_name = {"stream": "r01i_pmc_traffic.json", "trilinear": "r01i_tri_pmc_traffic.json"}.get(affine, "none")
+        pmc_name = {"stream": "r01i_pmc_traffic.json", "trilinear": "r01j_pmc_traffic.json"}.get(affine, "none")
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if (os.path.exists(pmc) and n == 64 and P == 4 and args.block_elems is None and args.waves is None
                 and not args.deterministic and args.dtype == "f64" and args.model == "linear" and world == 1
@@ -379,7 +389,7 @@ def main():
             "finite_nonzero_solution": finite,
         }
         for e2, aff2, fin2 in others:
-            b2 = 4 * (rho_e * (s + 4 + (0 if aff2 != "stream" else 6 * s) + extra_x * s) + s + (12 + extra_v) * s)
+            b2 = 4 * (rho_e * (s + 4 + geo_b[aff2] + extra_x * s) + s + (12 + extra_v) * s)
             v2 = ndofs_global * args.steps / e2
             key = {"affine": "other_geometry", "trilinear": "trilinear_geometry", "stream": "streamed_geometry"}[aff2]
             out[key] = {"geometry": GEOM_NAMES[aff2], "value": v2, "unit": "DOF-updates/s",

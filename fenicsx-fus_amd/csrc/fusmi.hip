@@ -1492,9 +1492,13 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   // elements, small enough for four / three / two blocks per CU at the register budgets of those
   // kernels (p=5: +3-5 % over 12, p=6: +19-20 %; profiles/r01_block_sweep.txt)
   static const int be_aff_hi[8] = {0, 0, 0, 0, 0, 8, 8, 8};
-  const int be_affine = (op->tdim == 3 && op->P >= 5) ? be_aff_hi[op->P] : be_stream / 2;
+  const int be_affine = (op->tdim == 3 && op->P >= 5) ? ((op->dtype == FUS_F32 && op->P == 5) ? 16 : be_aff_hi[op->P])
+                                                      : be_stream / 2;
   const int gcs = affine_mesh ? 7 : (trilinear_mesh ? 21 : 0);
-  const int be_tri = be_affine;
+  // fp32 halves the LDS per block: the trilinear kernel takes 16 elements at p >= 5 (+9-12 %), the
+  // affine one at p = 5 only (+5 %; 16 is 2-9 % slower at p = 6, 7)
+  const bool hi32 = op->dtype == FUS_F32 && op->tdim == 3 && op->P >= 5;
+  const int be_tri = hi32 ? 16 : be_affine;
   const int be0 = c->block_elems > 0
                       ? c->block_elems
                       : (trilinear_mesh && op->P == 4 && op->dtype == FUS_F64 && op->nfields == 1 && c->waves <= 0) ? 32

@@ -149,6 +149,7 @@ def main():
                          "does by default on any first-order hexahedral mesh with non-affine cells, taken here without "
                          "the affine shortcut the synthetic box would allow; stream: per-point G from HBM (the reference's "
                          "data path); auto: the library default (this box is affine: 7 numbers per cell)")
+    ap.add_argument("--graph", type=int, default=None, help="1: replay each RK step as one hipGraph (launch-bound sizes)")
     ap.add_argument("--both-geometries", type=int, default=1,
                     help="1: at N=1 also time the other two geometry paths -> 'other_geometry' (affine), 'trilinear_geometry', "
                          "'streamed_geometry'; 2: at every N; 0: never")
@@ -190,6 +191,8 @@ def main():
     import fenicsxfus_amd as fa
 
     ctx = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves, deterministic=args.deterministic, geometry=args.geometry)
+    if args.graph is not None:
+        ctx.set_option("graph", args.graph)
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run
     transport = args.transport
     if args.halo_loopback:

@@ -142,6 +142,7 @@ struct fus_ctx
   hipEvent_t ev_packed = nullptr, ev_recv = nullptr;
   int deterministic = 0;  // 1: conflict-free rounds (bitwise reproducible); 0: LDS atomics
   int fields = 1;         // operator inputs per block pass the ops are sized for (2: Lossy)
+  int graph = 0;          // 1: replay the RK step as one hipGraph (launch-bound sizes)
   int geometry = 0;       // 0: auto (affine cells: 7 numbers per cell; other first-order hexahedra: the
                           // cell's trilinear map, G recomputed per point; else streamed), 1: always
                           // stream G, 2: as auto without the affine shortcut
@@ -217,6 +218,8 @@ struct fus_model
   fus_ctx* ctx;
   fus_op* op;
   int kind;
+  hipGraphExec_t gexec = nullptr;  // option "graph": the RK step as one executable graph (see d_model_step)
+  int64_t gsteps = 0;              // steps taken since init / set (the first one is launched directly)
   double freq, amp, speed;
   void *u0 = nullptr, *v0 = nullptr, *u_ = nullptr, *v_ = nullptr, *un = nullptr, *vn = nullptr,
        *b = nullptr, *minv = nullptr, *m = nullptr, *coef = nullptr, *coef2 = nullptr;
@@ -1388,10 +1391,56 @@ static int d_model_setup(fus_model* m, const void* c0, const void* rho0, const v
   FUS_DEGREE(d, m->op->dtype, m->op->P);
   return d->model_setup(m, c0, rho0, delta0, beta0, nf, fc, fl, ft);
 }
+// One RK step.  Option "graph" (one rank, no per-kernel events): the step's launches are captured
+// into a graph and replayed as ONE submission -- for launch-bound sizes (BASELINE config 1: eight
+// kernels of a few microseconds).  The stage scalars (source value at the stage times) are kernel
+// arguments, so every step is re-captured and the executable graph updated in place
+// (hipGraphExecUpdate: same topology, new arguments); the first step after init / set runs directly
+// (it has one more launch, k_boundary_partial, and sets the kernels' attributes).
 static int d_model_step(fus_model* m, double t, double dt)
 {
   FUS_DEGREE(d, m->op->dtype, m->op->P);
-  return d->model_step(m, t, dt);
+  fus_ctx* c = m->ctx;
+  const bool graphed = c->graph && c->nranks <= 1 && !c->prof && m->op->neigh.empty() && m->gsteps > 0;
+  ++m->gsteps;
+  if (!graphed)
+    return d->model_step(m, t, dt);
+  HIPCHK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+  const int r = d->model_step(m, t, dt);
+  hipGraph_t g = nullptr;
+  const hipError_t e = hipStreamEndCapture(c->stream, &g);
+  if (r != FUS_OK || e != hipSuccess || !g)
+  {
+    if (g)
+      (void)hipGraphDestroy(g);
+    return r != FUS_OK ? r : fail(FUS_ERR_HIP, std::string("graph capture of the RK step failed: ") + hipGetErrorString(e));
+  }
+  if (m->gexec)
+  {
+    hipGraphNode_t bad = nullptr;
+    hipGraphExecUpdateResult res;
+    if (hipGraphExecUpdate(m->gexec, g, &bad, &res) != hipSuccess)
+    {
+      (void)hipGetLastError();
+      (void)hipGraphExecDestroy(m->gexec);
+      m->gexec = nullptr;
+    }
+  }
+  if (!m->gexec)
+  {
+    const hipError_t ei = hipGraphInstantiate(&m->gexec, g, nullptr, nullptr, 0);
+    if (ei != hipSuccess)
+    {
+      (void)hipGraphDestroy(g);
+      m->gexec = nullptr;
+      return fail(FUS_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(ei));
+    }
+  }
+  const hipError_t el = hipGraphLaunch(m->gexec, c->stream);
+  (void)hipGraphDestroy(g);
+  if (el != hipSuccess)
+    return fail(FUS_ERR_HIP, std::string("hipGraphLaunch: ") + hipGetErrorString(el));
+  return FUS_OK;
 }
 static int d_stage_begin(fus_model* m, int i, double t, double dt)
 {
@@ -1614,6 +1663,8 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
   }
   else if (!strcmp(key, "deterministic"))
     c->deterministic = value != 0;
+  else if (!strcmp(key, "graph"))
+    c->graph = value != 0;
   else if (!strcmp(key, "geometry"))
   {
     if (value < 0 || value > 2)
@@ -2303,6 +2354,8 @@ int fus_model_destroy(fus_model* m)
     return FUS_OK;
   (void)hipSetDevice(m->ctx->device);
   (void)hipStreamSynchronize(m->ctx->stream);
+  if (m->gexec)
+    (void)hipGraphExecDestroy(m->gexec);
   for (void* q : m->allocs)
     (void)hipFree(q);
   delete m;
@@ -2319,6 +2372,7 @@ int fus_model_init(fus_model* m)
     HIPCHK(hipMemsetAsync(v, 0, bytes, m->ctx->stream));
   m->initialised = true;
   m->bnd_valid = false;  // state changed: the pseudo boundary partials are stale
+  m->gsteps = 0;
   return FUS_OK;
 }
 
@@ -2396,6 +2450,7 @@ int fus_model_set(fus_model* m, int which, const void* in, int space)
   HIPCHK(hipSetDevice(m->ctx->device));
   m->initialised = true;
   m->bnd_valid = false;  // state changed: the pseudo boundary partials are stale
+  m->gsteps = 0;
   return m->op->dtype == FUS_F64
              ? model_getset<double>(m, which, const_cast<void*>(in), space, true)
              : model_getset<float>(m, which, const_cast<void*>(in), space, true);

@@ -68,6 +68,9 @@ int fus_synchronize(fus_ctx* ctx);
  * interface DOFs are launched first and the exchange overlaps the remaining blocks; default 0: it
  * overlaps the shared-DOF kernel only), "halo_loopback" (1: timing rehearsal on one GPU -- a 1-rank
  * communicator, every send/receive goes to the own rank; results are not the physical ones).
+ * "graph" (1: on one rank the launches of an RK step are captured and replayed as one hipGraph, the
+ * executable graph being updated in place with each step's stage scalars; for launch-bound sizes
+ * such as BASELINE config 1; default 0).
  * Unknown keys -> FUS_ERR_ARG. */
 int fus_set_option(fus_ctx* ctx, const char* key, int64_t value);
 

@@ -570,3 +570,40 @@ def test_mesh_size_norm_and_allreduce(orc):
     assert abs(d2.hmin() - h) < 1e-14
     d2.close()
     c.close()
+
+
+@pytest.mark.parametrize("tdim", [2, 3])
+def test_graph_replay_of_the_rk_step(orc, tdim):
+    """Option "graph": the RK step captured and replayed as one hipGraph (updated in place with each
+    step's stage scalars) gives the bits of the directly launched step (deterministic accumulation),
+    also across a re-initialisation and a change of dt."""
+    L = 0.012
+    n = (6, 5, 4)[:tdim] if tdim == 3 else (9, 7)
+    pr = Problem(orc, n, 4, hi=[L] * tdim, perturb=0.1)
+    nc = pr.mesh.num_cells
+    tags = tag_box_boundary(pr.mesh)
+    c0, rho0 = np.full(nc, 1500.0), np.full(nc, 1000.0)
+    dt = 0.5 * (L / n[0]) / (1500.0 * 16)
+    res = []
+    for graph in (0, 1):
+        c = fa.Context(0, deterministic=1)
+        c.set_option("graph", graph)
+        m = fa.LinearSpectralExplicit(pr.mesh, tags, 4, c0, rho0, 0.5e6, 6e4, 1500.0, 4, dt, V=pr.V, ctx=c)
+        m.init()
+        m.rk4_steps(0.0, dt, 25)
+        a = m.u_sol().x.array.copy()
+        un, vn, _ = m.rk(25 * dt, 25 * dt + 7.5 * dt)     # last step shorter: one more launch in that step
+        b = un.x.array.copy()
+        m.init()                                          # back to zero state: first step is launched directly again
+        m.rk4_steps(0.0, dt, 3)
+        res.append((a, b, m.u_sol().x.array.copy()))
+        m.close()
+        c.close()
+    for x, y in zip(*res):
+        assert np.abs(x).max() > 0 and np.array_equal(x, y)
+    # and against the oracle
+    mv, src, absb, coeff = pr.linear_model_vectors(c0, rho0, tags)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    # 25 full steps (+ a ~1e-12 dt remainder step, far below the tolerance)
+    orc.linear_rk4(tdim, pr.N, pr.dm, pr.G, pr.D, coeff, mv, src, absb, 0.5e6, 6e4, 1500.0, 0.0, 25 * dt * (1 + 1e-12), dt, u, v)
+    assert relmax(res[1][0], u) < TOL_RK

@@ -8,7 +8,7 @@ import numpy as np
 sys.path.insert(0, "fenicsx-fus_amd")
 import fenicsxfus_amd as fa  # noqa: E402
 
-for n in (128, 512, 2048):
+for n, graph in ((128, 0), (128, 1), (512, 0), (512, 1), (2048, 0)):
     L, P = 0.12 * n / 128, 4
     mesh = fa.BoxMesh([0, 0], [L, L], (n, n))
     V = fa.FunctionSpace(mesh, P)
@@ -16,6 +16,7 @@ for n in (128, 512, 2048):
     nc = mesh.num_cells
     dt = 0.5 * (L / n) / (1500.0 * P**2)
     ctx = fa.Context(0)
+    ctx.set_option("graph", graph)        # 1: each RK step replayed as one hipGraph
     m = fa.LinearSpectralExplicit(mesh, tags, P, np.full(nc, 1500.0), np.full(nc, 1000.0), 0.5e6, 6e4, 1500.0, 4, dt,
                                   V=V, ctx=ctx)
     m.init()
@@ -26,7 +27,7 @@ for n in (128, 512, 2048):
     m.rk4_steps(20 * dt, dt, steps)
     ctx.synchronize()
     el = time.perf_counter() - t0
-    print(f"{n}x{n} quads Q4: {V.num_dofs} dofs, {1e3 * el / steps:.4f} ms/step, {V.num_dofs * steps / el:.4e} DOF-updates/s, "
+    print(f"{n}x{n} quads Q4 graph={graph}: {V.num_dofs} dofs, {1e3 * el / steps:.4f} ms/step, {V.num_dofs * steps / el:.4e} DOF-updates/s, "
           f"{640.0 * V.num_dofs * steps / el / 8e12:.3f} of 8 TB/s at B = 640 B", flush=True)
     m.close()
     ctx.close()

@@ -796,7 +796,11 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
       }
 #pragma unroll
     for (int u = 0; u < US; ++u)
+#if defined(FUS_ABLATE) && FUS_ABLATE == 3  // timing experiment: shared-dof values from a contiguous range, no index list
+      gi[u] = int_off + ((tid + u * nthr < sh.nint) ? tid + u * nthr : 0);
+#else
       gi[u] = (tid + u * nthr < nsh) ? gix[tid + u * nthr] : 0;
+#endif
 #pragma unroll
     for (int u = 0; u < UL; ++u)
       if (tid + u * nthr < n16)

@@ -338,10 +338,10 @@ def main():
         achieved = alg_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
         value = (ndl if args.halo_loopback else ndofs_global) * args.steps / elapsed
         # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
-        # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01k_pmc_traffic.json (trilinear), r01i_pmc_traffic.json (streamed), tools/gpu_profile.sh); only quoted
+        # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01l_pmc_traffic.json (trilinear), r01i_pmc_traffic.json (streamed), tools/gpu_profile.sh); only quoted
         # for the configuration those passes were taken on
         traffic = None
-        pmc_name = {"stream": "r01i_pmc_traffic.json", "trilinear": "r01k_pmc_traffic.json"}.get(affine, "none")
+        pmc_name = {"stream": "r01i_pmc_traffic.json", "trilinear": "r01l_pmc_traffic.json"}.get(affine, "none")
         pmc = os.path.join(ROOT, "profiles", pmc_name)
         if (os.path.exists(pmc) and n == 64 and P == 4 and args.block_elems is None and args.waves is None
                 and not args.deterministic and args.dtype == "f64" and args.model == "linear" and world == 1

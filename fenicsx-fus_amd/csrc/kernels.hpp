@@ -430,7 +430,10 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
     // the (b, c) owner: 5 reads + 5 writes + 5 reads per direction instead of 25 reads + the lane's
     // derivative rows -- the element trips of the per-cell geometry kernels are bound by the LDS port.
     // (degree 7 keeps the tile-read form: re-mapped it measured 5 % (trilinear) / 14 % (affine) slower)
-    constexpr bool REMAP = FUS_REMAP_ON && (GEOM != GEOM_STREAM) && N <= 7;
+#ifndef FUS_REMAP_STREAM
+#define FUS_REMAP_STREAM 0  // the streamed kernel sits on the bandwidth roofline: measured separately
+#endif
+    constexpr bool REMAP = FUS_REMAP_ON && (GEOM != GEOM_STREAM || FUS_REMAP_STREAM) && N <= 7;
     if constexpr (REMAP)
     {
 #pragma unroll
@@ -492,7 +495,10 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
           T G6[6];
 #pragma unroll
           for (int gi = 0; gi < 6; ++gi)
-            G6[gi] = gc_l[in.er * 7 + gi] * w3[a];
+          {
+            const int v = gi * N + a;
+            G6[gi] = (GEOM == GEOM_STREAM) ? in.g[v / VW][v % VW] : gc_l[in.er * 7 + gi] * w3[a];
+          }
           const T w0 = F0[a], w1 = F1[a], w2 = F2[a];
           F0[a] = cf * (G6[0] * w0 + G6[1] * w1 + G6[2] * w2);
           F1[a] = cf * (G6[1] * w0 + G6[3] * w1 + G6[4] * w2);

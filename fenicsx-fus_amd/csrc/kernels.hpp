@@ -429,13 +429,18 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
     // them), contracts with the derivative table in scalar registers and writes the result back for
     // the (b, c) owner: 5 reads + 5 writes + 5 reads per direction instead of 25 reads + the lane's
     // derivative rows -- the element trips of the per-cell geometry kernels are bound by the LDS port.
-    // (degree 7 keeps the tile-read form: re-mapped it measured 5 % (trilinear) / 14 % (affine) slower)
+#ifndef FUS_REMAP_MAXN
+#define FUS_REMAP_MAXN 7  // degree 7 (N = 8) keeps the tile-read form: re-mapped it measured 5-14 % slower
+#endif
 #ifndef FUS_REMAP_STREAM
 #define FUS_REMAP_STREAM 0  // the streamed kernel sits on the bandwidth roofline: measured separately
 #endif
-    constexpr bool REMAP = FUS_REMAP_ON && (GEOM != GEOM_STREAM || FUS_REMAP_STREAM) && N <= 7;
+    constexpr bool REMAP = FUS_REMAP_ON && (GEOM != GEOM_STREAM || FUS_REMAP_STREAM) && N <= FUS_REMAP_MAXN;
     if constexpr (REMAP)
     {
+      // plane stride of the tile: N^2, padded by one where the re-mapped accesses (lanes (b, c) at
+      // b * TS + ...) would otherwise fall on the same LDS banks for every b (N = 8: 8-way, N = 4: 2-way)
+      constexpr int TS = (N == 8 || N == 4) ? N2 + 1 : N2;
 #pragma unroll
       for (int q = 0; q < N; ++q)
       {
@@ -447,14 +452,14 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
       }
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        sA[a * N2 + p] = X[a];
+        sA[a * TS + p] = X[a];
       FUS_WAVE_SYNC();
       T Tb[N], Uc[N];
 #pragma unroll
       for (int k = 0; k < N; ++k)
       {
-        Tb[k] = sA[b * N2 + k * N + c];
-        Uc[k] = sA[b * N2 + c * N + k];
+        Tb[k] = sA[b * TS + k * N + c];
+        Uc[k] = sA[b * TS + c * N + k];
       }
       FUS_WAVE_SYNC();
 #pragma unroll
@@ -464,12 +469,12 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
         for (int k = 0; k < N; ++k)
           acc += Dk.d[q * N + k] * Tb[k];
-        sA[b * N2 + q * N + c] = acc;  // d/dX1 at point (b, q, c)
+        sA[b * TS + q * N + c] = acc;  // d/dX1 at point (b, q, c)
       }
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        F1[a] = sA[a * N2 + p];
+        F1[a] = sA[a * TS + p];
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int q = 0; q < N; ++q)
@@ -478,12 +483,12 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
         for (int k = 0; k < N; ++k)
           acc += Dk.d[q * N + k] * Uc[k];
-        sA[b * N2 + c * N + q] = acc;  // d/dX2 at point (b, c, q)
+        sA[b * TS + c * N + q] = acc;  // d/dX2 at point (b, c, q)
       }
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        F2[a] = sA[a * N2 + p];
+        F2[a] = sA[a * TS + p];
       // stiffness::transform (spectral_op.hpp:113-130)
 #pragma unroll
       for (int a = 0; a < N; ++a)
@@ -509,11 +514,11 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        sA[a * N2 + p] = F1[a];
+        sA[a * TS + p] = F1[a];
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int k = 0; k < N; ++k)
-        Tb[k] = sA[b * N2 + k * N + c];
+        Tb[k] = sA[b * TS + k * N + c];
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int j = 0; j < N; ++j)
@@ -522,13 +527,13 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
         for (int q = 0; q < N; ++q)
           acc += Dk.d[q * N + j] * Tb[q];
-        sA[b * N2 + j * N + c] = acc;
+        sA[b * TS + j * N + c] = acc;
       }
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
       {
-        T acc = sA[a * N2 + p];
+        T acc = sA[a * TS + p];
 #pragma unroll
         for (int q = 0; q < N; ++q)
           acc += Dk.d[q * N + a] * F0[q];
@@ -537,11 +542,11 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        sA[a * N2 + p] = F2[a];
+        sA[a * TS + p] = F2[a];
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int k = 0; k < N; ++k)
-        Uc[k] = sA[b * N2 + c * N + k];
+        Uc[k] = sA[b * TS + c * N + k];
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int j = 0; j < N; ++j)
@@ -550,12 +555,12 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
         for (int q = 0; q < N; ++q)
           acc += Dk.d[q * N + j] * Uc[q];
-        sA[b * N2 + c * N + j] = acc;
+        sA[b * TS + c * N + j] = acc;
       }
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        Y[a] += sA[a * N2 + p];
+        Y[a] += sA[a * TS + p];
     }
     else
     {
@@ -857,7 +862,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   T* y_l = x_l + A.lds_nloc;
   T* x2_l = y_l + A.lds_nloc;                               // second input (NF == 2 only)
   T* scratch = x2_l + (NF == 2 ? A.lds_nloc : 0);
-  T* D_l = scratch + (size_t)A.waves * EPW * Nd;           // derivative table
+  T* D_l = scratch + (size_t)A.waves * EPW * (Nd + N);     // derivative table (tiles: Nd + N each, see elem_compute REMAP)
   T* cf_l = D_l + N2;                                       // per-element coefficient(s)
   T* cf2_l = cf_l + A.lds_nelem;
   constexpr int GCS = geom_cell_stride(GEOM);               // per-cell geometry numbers (7 / 21 / 0)
@@ -1080,7 +1085,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
         rt_l[k] = A.rounds[sh.rounds_off + k];
   }
 
-  T* sA = scratch + (size_t)(wave * EPW + (active ? s : 0)) * Nd;
+  T* sA = scratch + (size_t)(wave * EPW + (active ? s : 0)) * (Nd + N);
   T* sB = sA;  // single exchange tile per element slot
 
   // lane-dependent rows/columns of the derivative table (tiny, cache resident)

@@ -4,27 +4,47 @@
     python bench.py --gpus N --steps K --warmup W
 
 One "step" = one full classical RK4 step (4 stages: stiffness action + shared-DOF reduction +
-boundary terms + fused stage update) of the Linear acoustic model on BASELINE.json configs[1]:
-3-D homogeneous water box, 64^3 hexes, p=4, fp64 (16 974 593 DOFs per GPU).  At N>1 each rank owns
-a 64^3 x-slab of a (64 N) x 64 x 64 box (weak scaling) and exchanges one interface plane per
-neighbour per stage over RCCL.  All state is resident in HBM when the timed region starts.
+boundary terms + fused stage update) of the Linear acoustic model.
+
+Workloads (config.workload names the one that ran):
+  default            BASELINE.json configs[1]: 3-D homogeneous water box, 64^3 hexes, p=4, fp64
+                     (16 974 593 DOFs per GPU); at N>1 each rank owns a 64^3 x-slab of a
+                     (64 N) x 64 x 64 box (weak scaling) and exchanges one interface plane per
+                     neighbour per stage over RCCL.
+  --cells 128 --P 7  configs[2] (single GPU).
+  --global-cells 256 --P 4 --medium skull            configs[3]: a fixed 256^3 box cut into N x-slabs
+                     (strong scaling; 8 slabs of 32 x 256 x 256), heterogeneous c / rho map.
+  --global-cells 256 --P 6 --dtype f32               configs[4].
+All state is resident in HBM when the timed region starts.  The timed region is K steps, bracketed
+by barrier + synchronize; it is repeated --repeats times (each repeat continues the same simulation)
+and `value` comes from the MEDIAN repeat, with min / max beside it.
+
 The headline goes through the library's kernel for general first-order hexahedral meshes (J and G
 recomputed per point from each cell's trilinear map, --geometry trilinear: the synthetic box is not
 allowed its affine shortcut); the reference's data path (per-point G streamed from HBM) and the
 affine path are timed beside it at N=1 ('streamed_geometry', 'other_geometry').
 
-Prints ONE JSON line on rank 0 (see the contract in the task statement) including
-  roofline     -- the dominant kernel (block stiffness operator): algorithmic bytes per launch
-                  (SURVEY 8d stiffness term: rho_e (s + 4 + g) + s per DOF, g = the path's geometry
-                  bytes per element-DOF: 6 s streamed, 21 s / N^3 trilinear, 7 s / N^3 affine; plus
-                  the fused stage update of the interior DOFs) / its average duration measured
-                  with HIP events on the library's stream
+Prints ONE JSON line on rank 0 including
+  roofline     -- the dominant kernel (block stiffness operator + fused stage update):
+                  `achieved` = algorithmic bytes per launch (rho_e (s + 4 + g) + s per DOF,
+                  g = the path's geometry bytes per element-DOF: 6 s streamed, 21 s / N^3 trilinear,
+                  7 s / N^3 affine; plus 12 s for each interior DOF the fused update finishes) / its
+                  average duration measured with HIP events on the library's stream;
+                  `traffic` = HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 +
+                  WRITE_SIZE, separate passes) -- measured live by child processes at N=1
+                  (--traffic live) or taken from the committed profile of the same command;
+                  `frac_real` = traffic / duration / 8 TB/s: the rate at which the kernel really moves bytes.
   cpu_baseline -- the CPU oracle (port of the reference loop, -Ofast) timed on this host
 """
 import argparse
+import csv
+import glob
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -34,26 +54,60 @@ for p in (ROOT, os.path.join(ROOT, "fenicsx-fus_amd")):
 
 import numpy as np  # noqa: E402
 
+WATER = (1500.0, 1000.0)
+# tag -> (c, rho) of the reference's layered head model
+# (cpp/fenicsx-sf/experiments/measure_vector_assembly_speed/main.cpp:43-83, 126-160)
+LAYERS = [(1500.0, 1000.0), (1610.0, 1090.0), (2800.0, 1850.0), (2300.0, 1700.0), (2800.0, 1850.0), (1560.0, 1040.0)]
 
-def workload(n_per_gpu, P, rank, size, dtype=np.float64):
-    """SURVEY 8d synthetic inputs: box edge 0.12 m per 64 cells, water, source on x=0 (tag 1),
-    absorbing elsewhere (tag 2), f = 0.5 MHz, p0 = 60 kPa, CFL 0.5 snapped to steps/period."""
+
+def medium(kind, mesh, L):
+    """Per-cell (c, rho): water; "skull" = cortical-bone slab x in [0.4 L, 0.5 L] in water
+    (BM7-SC1/main.cpp:37-40); "layers" = the six-material head model as x-slabs."""
+    nc = mesh.num_cells
+    c, rho = np.full(nc, WATER[0]), np.full(nc, WATER[1])
+    if kind == "water":
+        return c, rho
+    cx = mesh.cell_centroids()[:, 0]
+    if kind == "skull":
+        sel = (cx > 0.4 * L) & (cx < 0.5 * L)
+        c[sel], rho[sel] = 2800.0, 1850.0
+    else:
+        edges = np.array([0.0, 0.30, 0.36, 0.42, 0.50, 0.56, 1.0001]) * L
+        tag = np.clip(np.searchsorted(edges, cx, side="right") - 1, 0, 5)
+        tab = np.array(LAYERS)
+        c, rho = tab[tag, 0].copy(), tab[tag, 1].copy()
+    return c, rho
+
+
+def workload(args, rank, size, dtype=np.float64, n_override=None):
+    """SURVEY 8d synthetic inputs: box edge 0.12 m per 64 cells, source on x=0 (tag 1), absorbing
+    elsewhere (tag 2), f = 0.5 MHz, p0 = 60 kPa, CFL 0.5 with the largest sound speed, snapped to an
+    integer number of steps per period."""
     import fenicsxfus_amd as fa
 
-    L1 = 0.12 * n_per_gpu / 64.0
-    mesh = fa.BoxMesh([0, 0, 0], [L1 * size, L1, L1], (n_per_gpu * size, n_per_gpu, n_per_gpu), rank=rank,
-                      size=size, dtype=dtype)
+    P = args.P
+    if args.global_cells and n_override is None:        # strong scaling: a fixed global box in `size` x-slabs
+        g = args.global_cells
+        L = 0.12 * g / 64.0
+        mesh = fa.BoxMesh([0, 0, 0], [L, L, L], (g, g, g), rank=rank, size=size, dtype=dtype)
+        h, Lx = L / g, L
+    else:                                               # weak scaling: n^3 cells per rank
+        n = n_override or args.cells
+        L1 = 0.12 * n / 64.0
+        mesh = fa.BoxMesh([0, 0, 0], [L1 * size, L1, L1], (n * size, n, n), rank=rank, size=size, dtype=dtype)
+        h, Lx = L1 / n, L1 * size
     V = fa.FunctionSpace(mesh, P)
     tags = fa.tag_box_boundary(mesh)
-    c0, rho0, freq, p0 = 1500.0, 1000.0, 0.5e6, 60000.0
-    h = L1 / n_per_gpu
-    dt = 0.5 * h / (c0 * P**2)
+    c, rho = medium(args.medium, mesh, Lx)
+    cmax = max(v[0] for v in ([WATER] if args.medium == "water" else LAYERS))
+    freq, p0 = 0.5e6, 60000.0
+    dt = 0.5 * h / (cmax * P**2)
     period = 1.0 / freq
     dt = period / np.ceil(period / dt)
-    return mesh, V, tags, c0, rho0, freq, p0, dt
+    return mesh, V, tags, c, rho, freq, p0, dt
 
 
-def cpu_baseline(P, n, steps):
+def cpu_baseline(args, n, steps):
     """Oracle (restatement of Linear.hpp:228-314 + spectral_op.hpp:173-243, -Ofast -march=native) on a
     bounded sample of the same workload, timed on this host: threaded like the reference's one MPI
     rank per core (one contiguous x-slab of cells per thread) and, for scale,
@@ -62,12 +116,12 @@ def cpu_baseline(P, n, steps):
 
     oracle.build()
 
-    mesh, V, tags, c0, rho0, freq, p0, dt = workload(n, P, 0, 1)
+    P = args.P
+    mesh, V, tags, c, r, freq, p0, dt = workload(args, 0, 1, n_override=n)
     nc, nd = mesh.num_cells, V.num_dofs
     wts = oracle.gll_weights_at(V.nodes1d)
     D = oracle.dphi(V.nodes1d)
     G, detJ = oracle.geometry(3, mesh.geometry.x, mesh.geometry.dofmap, V.nodes1d, wts)
-    c, r = np.full(nc, c0), np.full(nc, rho0)
     m = oracle.mass(3, P + 1, V.tensor_dofmap, detJ, 1.0 / (r * c * c), np.ones(nd), np.zeros(nd))
     fd = lambda tag, cc: oracle.facet_diag(3, tags.cells[tags.find(tag)], tags.local_facets[tags.find(tag)], cc,  # noqa
                                            mesh.geometry.x, mesh.geometry.dofmap, V.nodes1d, wts, V.tensor_dofmap, nd)
@@ -80,17 +134,17 @@ def cpu_baseline(P, n, steps):
     layers = np.linspace(0, n, threads + 1).astype(np.int64) * (n * n)   # cells are x-major
     u, v = np.zeros(nd), np.zeros(nd)
     t0 = time.perf_counter()
-    ns = oracle.linear_rk4_mt(P + 1, V.tensor_dofmap, G, D, -1.0 / r, m, src, absb, freq, p0, c0, 0.0,
+    ns = oracle.linear_rk4_mt(P + 1, V.tensor_dofmap, G, D, -1.0 / r, m, src, absb, freq, p0, 1500.0, 0.0,
                               steps * dt * (1 - 1e-9), dt, u, v, layers, fast=True)
     el = time.perf_counter() - t0
-    s1 = max(2, steps // 8)
+    s1 = max(2, steps // 16)
     u1, v1 = np.zeros(nd), np.zeros(nd)
     t0 = time.perf_counter()
-    n1 = oracle.linear_rk4(3, P + 1, V.tensor_dofmap, G, D, -1.0 / r, m, src, absb, freq, p0, c0, 0.0,
+    n1 = oracle.linear_rk4(3, P + 1, V.tensor_dofmap, G, D, -1.0 / r, m, src, absb, freq, p0, 1500.0, 0.0,
                            s1 * dt * (1 - 1e-9), dt, u1, v1, fast=True)
     el1 = time.perf_counter() - t0
     return {"value": nd * ns / el, "unit": "DOF-updates/s", "cores": threads, "kind": "port",
-            "sample": f"{n}^3 hex p={P} fp64 ({nd} DOFs), {ns} RK4 steps, {el:.1f} s, oracle -Ofast, "
+            "sample": f"{n}^3 hex p={P} fp64 ({nd} DOFs, {args.medium}), {ns} RK4 steps, {el:.1f} s, oracle -Ofast, "
                       f"{threads} threads (one x-slab of cells each)",
             "single_thread_value": nd * n1 / el1}
 
@@ -133,12 +187,66 @@ GEOM_NAMES = {"stream": "general, G streamed (6 values per point from HBM: the r
                            "B_affine + 14 s / N^3 per element-DOF)"}
 
 
+def fused_kernel_filter(name, P, dtype):
+    """Kernel-trace / counter rows of the fused block kernel: k_block_op<T, P, OP=0 (stiffness), ATOMIC,
+    STAGE in {0, 1, 3}, ...> -- not the plain operator action (STAGE = -1)."""
+    t = "double" if dtype == "f64" else "float"
+    if f"k_block_op<{t}, {P}, 0, " not in name:
+        return False
+    targs = name.split("k_block_op<")[1].split(",")
+    return targs[4].strip() != "-1"
+
+
+def live_traffic(argv_tail, P, dtype):
+    """HBM bytes per launch of the fused block kernel, measured now: two child runs of this script under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, kernel-trace only beside them, the
+    program directly after `--`), FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM) prescribes for wide
+    coalesced streams on gfx950; counters are in KiB.  Runs before this process touches the GPU."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    per = {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix=f"fus_pmc_{ctr}_", dir="/tmp")
+        cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+               os.path.abspath(__file__), "--pmc-child", "--no-cpu", "--steps", "4", "--warmup", "1", "--repeats", "1",
+               "--both-geometries", "0", "--traffic", "none", *argv_tail]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        except subprocess.TimeoutExpired:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"{ctr} pass timed out"
+        files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            shutil.rmtree(d, ignore_errors=True)
+            return None, f"{ctr} pass failed (rc {r.returncode})"
+        tot, seen = 0.0, set()
+        for row in csv.DictReader(open(files[0])):
+            if row["Counter_Name"] == ctr and fused_kernel_filter(row["Kernel_Name"], P, dtype):
+                tot += float(row["Counter_Value"])
+                seen.add(row["Dispatch_Id"])
+        shutil.rmtree(d, ignore_errors=True)
+        if not seen:
+            return None, f"no fused block-kernel dispatch in the {ctr} pass"
+        per[ctr] = (tot / len(seen) * 1024.0, len(seen))
+    rd, wr = 2.0 * per["FETCH_SIZE"][0], per["WRITE_SIZE"][0]
+    return {"hbm_bytes_per_launch": rd + wr, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
+            "launches": per["FETCH_SIZE"][1]}, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--cells", type=int, default=64, help="cells per axis per GPU")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed K-step block is run this many times; value = median")
+    ap.add_argument("--cells", type=int, default=64, help="cells per axis per GPU (weak scaling)")
+    ap.add_argument("--global-cells", type=int, default=0,
+                    help="strong scaling: a fixed G^3 box cut into N x-slabs (BASELINE configs[3], [4]: 256)")
+    ap.add_argument("--medium", choices=["water", "skull", "layers"], default="water",
+                    help="skull: cortical-bone slab in water (BM7-SC1/main.cpp:37-40); layers: the reference's six-material "
+                         "head model as x-slabs (measure_vector_assembly_speed/main.cpp:43-83)")
     ap.add_argument("--P", type=int, default=4)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
     ap.add_argument("--block-elems", type=int, default=None)
@@ -160,12 +268,20 @@ def main():
                     help="linear is BASELINE's metric; lossy / westervelt (SURVEY 8f-1) are reported as diagnostics")
     ap.add_argument("--no-profile", action="store_true", help="diagnostic: no per-kernel HIP events in the timed region")
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
-                    help="N > 1 exchange: the library's RCCL send/recv (default; falls back to 'torch' if its "
-                         "communicator cannot be created) or torch.distributed P2P through the external-transport "
-                         "entry points (slower: the host drives every stage half)")
+                    help="N > 1 exchange: the library's RCCL send/recv (default) or torch.distributed P2P through the "
+                         "external-transport entry points (slower: the host drives every stage half)")
+    ap.add_argument("--overlap", choices=["ab", "on", "off"], default="ab",
+                    help="N > 1: launch the interface blocks first and overlap the exchange with the remaining blocks "
+                         "(option overlap_blocks). ab: time both during warm-up on this node's links, run the timed "
+                         "region with the faster, report both")
+    ap.add_argument("--traffic", choices=["live", "profile", "none"], default="live",
+                    help="roofline.traffic: live = two rocprofv3 --pmc child passes of this command before the run (N=1 "
+                         "only), profile = the committed profiles/ file of the same configuration, none")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-n", type=int, default=32)
-    ap.add_argument("--cpu-steps", type=int, default=400)
+    ap.add_argument("--cpu-n", type=int, default=64, help="cells per axis of the CPU sample (64 = the GPU workload itself)")
+    ap.add_argument("--cpu-steps", type=int, default=0,
+                    help="RK4 steps of the CPU sample; 0 = sized for about 15 s of threaded CPU work")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
     # stdout carries exactly one line, the JSON result: whatever libraries print on file descriptor 1
@@ -174,14 +290,34 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
-    import torch
-
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+
+    import torch
+
+    if torch.cuda.device_count() == 0:      # (counting devices does not initialise the GPU)
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+
+    # ---- live HBM traffic of the dominant kernel (child processes, before this one touches the GPU) ----
+    traffic, traffic_src = None, None
+    if (args.traffic == "live" and world == 1 and not launched and not args.pmc_child and not args.halo_loopback
+            and args.model == "linear"):
+        tail = ["--cells", str(args.cells), "--P", str(args.P), "--dtype", args.dtype, "--geometry", args.geometry,
+                "--medium", args.medium]
+        if args.global_cells:
+            tail += ["--global-cells", str(args.global_cells)]
+        for k, v in (("--block-elems", args.block_elems), ("--waves", args.waves), ("--deterministic", args.deterministic)):
+            if v is not None:
+                tail += [k, str(v)]
+        traffic, traffic_src = live_traffic(tail, args.P, args.dtype)
+        if traffic is None:
+            print(f"[bench] live traffic unavailable: {traffic_src}", file=sys.stderr)
+
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
     if "FUSMI_BENCH_DEVICE" in os.environ:   # rehearsal of N>1 on a one-GPU box
@@ -193,7 +329,6 @@ def main():
     ctx = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves, deterministic=args.deterministic, geometry=args.geometry)
     if args.graph is not None:
         ctx.set_option("graph", args.graph)
-    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run
     transport = args.transport
     if args.halo_loopback:
         assert world == 1 and not launched
@@ -204,12 +339,14 @@ def main():
             ctx.comm_init(1, 3, fa.Context.unique_id())
         args.both_geometries = 0
     ids2 = ids3 = [None]
+    dist = None
     if world > 1 or launched:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         if transport == "rccl":
+            # the library's own communicator; a failure here is fatal (exit non-zero, nothing is re-launched)
             try:
                 ids = [fa.Context.unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids, src=0)
@@ -218,12 +355,11 @@ def main():
                 dist.broadcast_object_list(ids2, src=0)
                 ids3 = [fa.Context.unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(ids3, src=0)
-            except fa.FusError as e:            # the library's own RCCL communicator could not be made
-                print(f"[bench rank {rank}] RCCL transport unavailable ({e}); using torch.distributed P2P", file=sys.stderr)
-                transport = "torch"
-                ctx = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves,
-                                 deterministic=args.deterministic, geometry=args.geometry)
-        if transport == "torch":
+            except fa.FusError as e:
+                print(f"[bench rank {rank}] RCCL communicator could not be created: {e}", file=sys.stderr)
+                sys.stderr.flush()
+                os._exit(3)
+        else:
             ctx.init_external(rank, world)
             args.both_geometries = 0
 
@@ -233,28 +369,35 @@ def main():
         torch.cuda.synchronize()
         ctx.synchronize()
 
-    P, n = args.P, args.cells
+    def max_over_ranks(x):
+        if world > 1 or launched:
+            tt = torch.tensor([x], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return x
+
+    P = args.P
     np_dtype = np.float64 if args.dtype == "f64" else np.float32
     if args.halo_loopback:
-        mesh, V, tags, c0, rho0, freq, p0, dt = workload(n, P, 1, 3, dtype=np_dtype)
+        mesh, V, tags, c0, rho0, freq, p0, dt = workload(args, 1, 3, dtype=np_dtype)
     else:
-        mesh, V, tags, c0, rho0, freq, p0, dt = workload(n, P, rank, world, dtype=np_dtype)
+        mesh, V, tags, c0, rho0, freq, p0, dt = workload(args, rank, world, dtype=np_dtype)
     nc = mesh.num_cells
     ndofs_global = V.dofmap.index_map.size_global
+    overlap_ab = {}
 
-    def run(context, steps, warmup, profile):
-        """Build the model on `context`, run warmup + timed steps; returns timings and model info."""
+    def run(context, steps, warmup, repeats, profile, headline=False):
+        """Build the model on `context`, run warmup, then `repeats` timed blocks of `steps` steps (each bracketed
+        by barrier + synchronize, max over ranks); returns the block times and model info."""
         if args.model == "linear":
-            model = fa.LinearSpectralExplicit(mesh, tags, P, np.full(nc, c0), np.full(nc, rho0), freq, p0, c0, 4, dt,
-                                              V=V, ctx=context)
+            model = fa.LinearSpectralExplicit(mesh, tags, P, c0, rho0, freq, p0, 1500.0, 4, dt, V=V, ctx=context)
         else:   # attenuating, weakly nonlinear water-like medium (BM7-SC1/main.cpp:43-46 style coefficients)
-            delta = np.full(nc, fa.compute_diffusivity_of_sound(2 * np.pi * freq, c0, 0.2))
+            delta = np.full(nc, fa.compute_diffusivity_of_sound(2 * np.pi * freq, 1500.0, 0.2))
             if args.model == "lossy":
-                model = fa.LossySpectralExplicit(mesh, tags, P, np.full(nc, c0), np.full(nc, rho0), delta, freq, p0, c0,
-                                                 4, dt, V=V, ctx=context)
+                model = fa.LossySpectralExplicit(mesh, tags, P, c0, rho0, delta, freq, p0, 1500.0, 4, dt, V=V, ctx=context)
             else:
-                model = fa.WesterveltSpectralExplicit(mesh, tags, P, np.full(nc, c0), np.full(nc, rho0), delta,
-                                                      np.full(nc, 3.5), freq, p0, c0, 4, dt, V=V, ctx=context)
+                model = fa.WesterveltSpectralExplicit(mesh, tags, P, c0, rho0, delta, np.full(nc, 3.5), freq, p0, 1500.0,
+                                                      4, dt, V=V, ctx=context)
         if transport == "torch" and (world > 1 or args.halo_loopback):
             # external transport: the host drives the two halves of every stage around a torch P2P exchange
             exch = torch_exchange(torch, dist if world > 1 else None, model, rank, loopback=args.halo_loopback)
@@ -269,24 +412,45 @@ def main():
         info = model.data.info()
         affine = model.data.geometry_mode()        # "stream" | "affine" | "trilinear"
         advance(0.0, warmup)
+        done = warmup
+
+        def timed(n):
+            nonlocal done
+            barrier()
+            t0 = time.perf_counter()
+            advance(done * dt, n)
+            barrier()
+            el = time.perf_counter() - t0
+            done += n
+            return max_over_ranks(el)
+
+        # exchange overlapped with the non-interface blocks, or only with the shared-dof stage kernel:
+        # decided on this node's links during warm-up (both timings are reported)
+        if headline and (world > 1 or args.halo_loopback) and transport == "rccl":
+            if args.overlap == "ab":
+                ab = max(3, min(steps, 10))
+                for name, flag in (("off", 0), ("on", 1), ("off", 0), ("on", 1)):
+                    context.set_option("overlap_blocks", flag)
+                    timed(1)
+                    overlap_ab.setdefault(name, []).append(1e3 * timed(ab) / ab)
+                best = min(overlap_ab, key=lambda k: min(overlap_ab[k]))
+                context.set_option("overlap_blocks", 1 if best == "on" else 0)
+                overlap_ab["chosen"] = best
+                timed(1)
+            else:
+                context.set_option("overlap_blocks", 1 if args.overlap == "on" else 0)
+                overlap_ab["chosen"] = args.overlap
+                timed(1)
         if profile:
             context.profile_enable(2)      # HIP events around the dominant kernel only (see fusmi.h)
-        barrier()
-        t0 = time.perf_counter()
-        advance(warmup * dt, steps)
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if world > 1 or launched:
-            tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            elapsed = float(tt.item())
+        times = [timed(steps) for _ in range(repeats)]
         prof = {}
         if profile:
             prof = {k: context.profile_get(k) for k in ("stiffness", "stiffness_if")}
             # per-kernel breakdown of a step: separate, untimed pass with events around every kernel
             nb = min(steps, 5)
             context.profile_enable(1)
-            advance((warmup + steps) * dt, nb)
+            advance(done * dt, nb)
             context.synchronize()
             prof["breakdown_ms_per_step"] = {k: context.profile_get(k)[0] / nb for k in
                                              ("stiffness", "stiffness_if", "shared", "boundary", "stage", "halo")}
@@ -294,9 +458,11 @@ def main():
         u = model.u_sol().x.array
         finite = bool(np.isfinite(u).all()) and float(np.abs(u).max()) > 0.0
         model.close()
-        return elapsed, prof, info, affine, finite
+        return times, prof, info, affine, finite
 
-    elapsed, prof, info, affine, finite = run(ctx, args.steps, args.warmup, not args.no_profile)
+    times, prof, info, affine, finite = run(ctx, args.steps, args.warmup, max(1, args.repeats), not args.no_profile,
+                                            headline=True)
+    elapsed = float(np.median(times))
     if args.no_profile:
         prof = {"stiffness": (0.0, 0), "stiffness_if": (0.0, 0), "breakdown_ms_per_step": {}}
     # secondary measurements: the same workload through the other geometry paths ("auto": the box
@@ -310,8 +476,8 @@ def main():
                               deterministic=args.deterministic, geometry=g)
             if world > 1:
                 ctx2.comm_init(rank, world, ids_k[0])
-            e2, _, _, aff2, fin2 = run(ctx2, args.steps, args.warmup, False)
-            others.append((e2, aff2, fin2))
+            t2, _, _, aff2, fin2 = run(ctx2, args.steps, args.warmup, min(3, max(1, args.repeats)), False)
+            others.append((float(np.median(t2)), aff2, fin2))
             ctx2.close()
 
     if rank == 0:
@@ -332,22 +498,33 @@ def main():
         b_general = 4 * (b_stiff + (12 + extra_v) * s)
         n_int = info["interior_dofs"]
         alg_launch = b_stiff * ndl + (12 + extra_v) * s * n_int
-        # N > 1: the stage's block kernel runs as two launches (interface blocks first, then the rest)
+        # N > 1: the stage's block kernel may run as two launches (interface blocks first, then the rest)
         k_ms, k_cnt = prof["stiffness"][0] + prof["stiffness_if"][0], prof["stiffness"][1]
         avg_ms = k_ms / max(k_cnt, 1)
         achieved = alg_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-        value = (ndl if args.halo_loopback else ndofs_global) * args.steps / elapsed
-        # HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of this
-        # command (FETCH_SIZE x2 on gfx950 + WRITE_SIZE; profiles/r01l_pmc_traffic.json (trilinear), r01i_pmc_traffic.json (streamed), tools/gpu_profile.sh); only quoted
-        # for the configuration those passes were taken on
-        traffic = None
-        pmc_name = {"stream": "r01i_pmc_traffic.json", "trilinear": "r01l_pmc_traffic.json"}.get(affine, "none")
-        pmc = os.path.join(ROOT, "profiles", pmc_name)
-        if (os.path.exists(pmc) and n == 64 and P == 4 and args.block_elems is None and args.waves is None
-                and not args.deterministic and args.dtype == "f64" and args.model == "linear" and world == 1
-                and not args.halo_loopback):
-            traffic = json.load(open(pmc))["k_block_op_fused"]["hbm_bytes_per_launch"]
-        triad = ctx.measure_bandwidth()     # measured streaming bandwidth of this device
+        ndofs_counted = ndl if args.halo_loopback else ndofs_global
+        value = ndofs_counted * args.steps / elapsed
+        if traffic is None and args.traffic != "none" and world == 1 and not args.halo_loopback and args.model == "linear":
+            # the committed rocprofv3 --pmc passes of this configuration (tools/gpu_profile.sh), if there are any
+            idx = os.path.join(ROOT, "profiles", "traffic_index.json")
+            key = f"{affine}:{args.cells if not args.global_cells else 'g%d' % args.global_cells}:p{P}:{args.dtype}"
+            if (os.path.exists(idx) and args.block_elems is None and args.waves is None and not args.deterministic
+                    and args.medium == "water"):
+                ent = json.load(open(idx)).get(key)
+                if ent:
+                    traffic = {"hbm_bytes_per_launch": ent["hbm_bytes_per_launch"]}
+                    traffic_src = f"profiles/{ent['file']} (separate rocprofv3 --pmc passes of this configuration)"
+        tbytes = traffic["hbm_bytes_per_launch"] if traffic else None
+        copy_bw = ctx.measure_bandwidth()     # measured streaming bandwidth of this device
+        mode = (f"strong scaling: {args.global_cells}^3 box in {world} x-slab(s)" if args.global_cells else
+                f"weak scaling: {args.cells}^3 cells per GPU")
+        cfgname = {(64, 0, 4, "f64", "water"): "BASELINE.json configs[1]", (128, 0, 7, "f64", "water"): "BASELINE.json configs[2]"}.get(
+            (args.cells, args.global_cells, P, args.dtype, args.medium))
+        if args.global_cells == 256 and P == 4 and args.dtype == "f64" and args.medium != "water":
+            cfgname = "BASELINE.json configs[3]"
+        if args.global_cells == 256 and P == 6 and args.dtype == "f32":
+            cfgname = "BASELINE.json configs[4]"
+        ms_rep = [1e3 * t / args.steps for t in times]
         out = {
             "metric": ("DOF-updates/sec (RK4 step) at p=4 hex fp64" if (P == 4 and args.dtype == "f64") else
                        f"DOF-updates/sec (RK4 step) at p={P} hex {args.dtype}") + ("" if args.model == "linear" else f" [{args.model} model]"),
@@ -358,39 +535,48 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.global_cells else "weak",
             "vs_baseline": None,
             "dtype": args.dtype,
             "data": "synthetic",
-            "config": {"workload": f"3D homogeneous wave, {n}^3 hex p={P} {args.dtype} per GPU, {args.model.capitalize()} RK4 "
-                                   + ("(BASELINE.json configs[1])" if (n, P, args.dtype) == (64, 4, "f64") else
-                                     "(BASELINE.json configs[2])" if (n, P, args.dtype) == (128, 7, "f64") else
-                                     "(parity/diagnostic configuration)"), "ndofs_global": int(ndofs_global),
-                       "cells_per_gpu": int(nc), "geometry": GEOM_NAMES[affine],
+            "config": {"workload": f"3D {'homogeneous' if args.medium == 'water' else 'heterogeneous (' + args.medium + ')'} wave, "
+                                   f"hex p={P} {args.dtype}, {args.model.capitalize()} RK4, {mode} "
+                                   f"({cfgname or 'parity/diagnostic configuration'})",
+                       "ndofs_global": int(ndofs_global), "cells_per_gpu": int(nc), "geometry": GEOM_NAMES[affine],
+                       "medium": args.medium,
                        "partition": "middle x-slab of 3, exchange looped back (diagnostic)" if args.halo_loopback
                        else f"x-slabs x{world}", "transport": transport if (world > 1 or args.halo_loopback) else "none",
                        "blocks": info["nblocks"],
                        "lds_bytes_per_block": info["lds_bytes"], "dt": dt},
+            # the timed K-step block repeated: value / ms_per_step are the median repeat
+            "repeats": {"n": len(times), "ms_per_step": ms_rep, "min": min(ms_rep), "max": max(ms_rep),
+                        "median": 1e3 * elapsed / args.steps,
+                        "value_min": ndofs_counted * args.steps / max(times), "value_max": ndofs_counted * args.steps / min(times)},
             "roofline": {"bound": "hbm", "kernel": f"k_block_op<{'double' if args.dtype == 'f64' else 'float'},{P},stiffness,+fused RK4 stage>", "achieved": achieved,
-                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": traffic,
-                         # measured streaming bandwidth of this device (nt triad, 3 x 512 MiB) and, where the PMC
-                         # traffic applies, the kernel's real HBM rate against it
-                         "measured_triad_GBps": triad, "frac_of_measured_triad": achieved / triad,
-                         "real_traffic_GBps": (traffic / (avg_ms * 1e-3) / 1e9) if (traffic and avg_ms > 0) else None,
-                         "real_traffic_frac_of_triad": (traffic / (avg_ms * 1e-3) / 1e9 / triad) if (traffic and avg_ms > 0) else None,
-                         "traffic_source": f"profiles/{pmc_name} (separate rocprofv3 --pmc passes)" if traffic else None,
+                         "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": tbytes,
+                         # the rate at which the kernel really moves bytes (PMC traffic / HIP-event duration)
+                         "real_traffic_GBps": (tbytes / (avg_ms * 1e-3) / 1e9) if (tbytes and avg_ms > 0) else None,
+                         "frac_real": (tbytes / (avg_ms * 1e-3) / 8e12) if (tbytes and avg_ms > 0) else None,
+                         "traffic_source": traffic_src if tbytes else None,
+                         "traffic_detail": traffic if tbytes else None,
+                         # measured streaming bandwidth of this device (16-byte copy/triad kernel of the library)
+                         "measured_stream_GBps": copy_bw,
+                         "real_traffic_frac_of_measured_stream": (tbytes / (avg_ms * 1e-3) / 1e9 / copy_bw) if (tbytes and avg_ms > 0) else None,
                          "algorithmic_bytes_per_launch": alg_launch, "interior_dofs": n_int, "avg_launch_ms": avg_ms,
                          "launches": k_cnt},
             "step_roofline": {"algorithmic_bytes_per_dof_update": b_general,
                               "achieved_GBps": b_general * value / world / 1e9,
-                              "frac_of_8TBps": b_general * value / world / 8e12,
-                              "frac_of_measured_triad": b_general * value / world / 1e9 / triad},
+                              "frac_of_8TBps": b_general * value / world / 8e12},
             # per-operator-action rate, comparable to the reference's logged stiffness actions
             # (2.0e9 DOF/s on 76 Icelake cores, p=4 fp64); here one action also does the fused stage update
             "operator_action_dofs_per_s": (ndl / (avg_ms * 1e-3)) if avg_ms > 0 else None,
             "kernel_ms_per_step": prof["breakdown_ms_per_step"],
             "finite_nonzero_solution": finite,
         }
+        if overlap_ab:
+            out["exchange_overlap"] = {"what": "ms per step with the exchange hidden behind the shared-dof stage kernel only "
+                                               "(off) or also behind the non-interface blocks (on), timed during warm-up",
+                                       **overlap_ab}
         for e2, aff2, fin2 in others:
             b2 = 4 * (rho_e * (s + 4 + geo_b[aff2] + extra_x * s) + s + (12 + extra_v) * s)
             v2 = ndofs_global * args.steps / e2
@@ -398,8 +584,9 @@ def main():
             out[key] = {"geometry": GEOM_NAMES[aff2], "value": v2, "unit": "DOF-updates/s",
                         "ms_per_step": 1e3 * e2 / args.steps, "algorithmic_bytes_per_dof_update": b2,
                         "frac_of_8TBps": b2 * v2 / world / 8e12, "finite_nonzero_solution": fin2}
-        if not args.no_cpu and args.dtype == "f64" and world == 1:   # CPU leg on rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(P, args.cpu_n, args.cpu_steps)
+        if not args.no_cpu and args.dtype == "f64" and world == 1 and not args.global_cells:   # CPU leg on rank 0 at N=1 only
+            nd_cpu = (args.cpu_n * P + 1) ** 3
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_n, args.cpu_steps or max(4, int(15 * 9e7 / nd_cpu)))
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or launched:
         dist.barrier()

@@ -15,6 +15,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <memory>
 #include <string>
@@ -211,6 +212,9 @@ struct fus_op
   int64_t n_halo = 0, n_uidx = 0;
   int32_t *d_pack_idx = nullptr, *d_uidx = nullptr, *d_uptr = nullptr, *d_usrc = nullptr;
   void *d_sendbuf = nullptr, *d_recvbuf = nullptr;
+  // the pseudo partial slots (next-stage boundary terms of shared boundary dofs) live in d_partial,
+  // i.e. per op, while several models may share one op: the model that wrote them last
+  const struct fus_model* bnd_owner = nullptr;
 };
 
 struct fus_model
@@ -319,12 +323,15 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
     Dk.d[i] = (T)op->D[i];
   for (int i = 0; i < N; ++i)
     Dk.w[i] = (T)op->wts[i], Dk.x[i] = (T)op->nodes[i];
-  static bool attr_set = false;  // per instantiation
-  if (!attr_set)
+  // the attribute is per device: one bit per device and instantiation (set again harmlessly if two
+  // threads race on the first launch)
+  static std::atomic<uint64_t> attr_set{0};
+  const uint64_t dev_bit = 1ull << (op->ctx->device & 63);
+  if (!(attr_set.load(std::memory_order_relaxed) & dev_bit))
   {
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+    attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
   }
   BlockArgs A = op->A;
   A.blk_begin = blk_begin;
@@ -1124,7 +1131,7 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
   hipStream_t st = m->ctx->stream;
   const int64_t nbs = m->nb - m->nb_int;
   const StageScalars sc_now = stage_scalars<T>(m, i, t, dt);
-  if (nbs > 0 && !(m->bnd_valid && m->bnd_tn == sc_now.tn))
+  if (nbs > 0 && !(m->bnd_valid && op->bnd_owner == m && m->bnd_tn == sc_now.tn))
   {
     ProfScope ps(m->ctx, "boundary");
     hipLaunchKernelGGL((k_boundary_partial<T>), dim3(nblk(nbs)), dim3(256), 0, st, nbs,
@@ -1191,6 +1198,7 @@ static int stage_end(fus_model* m, int i, double t, double dt)
     B.gnext = (T)scn.gval, B.dgnext = (T)scn.dgval;
     B.partial = static_cast<T*>(op->d_partial);
     m->bnd_valid = true, m->bnd_tn = scn.tn;
+    op->bnd_owner = m;
   }
   if (nloc > 0)
   {
@@ -1575,6 +1583,8 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
       continue;
     if (!err.empty())
       return fail(FUS_ERR_ARG, "layout: " + err);
+    if (too_big)
+      return fail(FUS_ERR_LIMIT, "a one-element block does not fit the LDS budget at this degree");
     break;
   }
   int r = d_op_setup(op);
@@ -2356,6 +2366,8 @@ int fus_model_destroy(fus_model* m)
   (void)hipStreamSynchronize(m->ctx->stream);
   if (m->gexec)
     (void)hipGraphExecDestroy(m->gexec);
+  if (m->op && m->op->bnd_owner == m)
+    m->op->bnd_owner = nullptr;
   for (void* q : m->allocs)
     (void)hipFree(q);
   delete m;

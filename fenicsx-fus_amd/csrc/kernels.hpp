@@ -116,18 +116,13 @@ enum
   OP_MASS = 1
 };
 
-// Phase timestamps of k_block_op (experiment builds only, -DFUS_TRACE): per block 8 slots of the
-// 100 MHz wall clock -- 0 start, 1 prologue done, 2 trips done, 3 epilogue done; 4 = CU id.
+// Phase timestamps of k_block_op exist in development builds only (build.py --dev -DFUS_TRACE pulls in
+// dev_trace.hpp); the product carries none.
 #ifdef FUS_TRACE
-__device__ unsigned long long g_fus_trace[65536 * 8];
-#define FUS_STAMP(blk, k)                                                                          \
-  do                                                                                               \
-  {                                                                                                \
-    if (threadIdx.x == 0 && (blk) < 65536)                                                         \
-      g_fus_trace[(size_t)(blk) * 8 + (k)] = wall_clock64();                                       \
-  } while (0)
+#include "dev_trace.hpp"
 #else
 #define FUS_STAMP(blk, k)
+#define FUS_TRACE_END(blk)
 #endif
 
 // waves per SIMD the GEOM_TRILINEAR block kernel is compiled for: 4 (128 VGPRs) up to degree 5, 2 above
@@ -279,11 +274,7 @@ __device__ __forceinline__ void elem_fetch(ElemIn<T, N, OP, GEOM, TD>& in, int e
     const int64_t e = elem_off + er;
     if (OP == OP_STIFFNESS)
     {
-#if defined(FUS_ABLATE) && FUS_ABLATE == 2  // timing experiment: no geometry stream
-      const T* Ge = geo + (e & 7) * (6 * Nd);
-#else
       const T* Ge = geo + e * (6 * Nd);
-#endif
 #pragma unroll
       for (int t = 0; t < NV; ++t)
         in.g[t] = *reinterpret_cast<const GV*>(Ge + (size_t)(t * N2 + p) * VW);
@@ -387,24 +378,6 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
   // and the transform coefficient becomes 1
   const T cf = (NF == 2) ? T(1) : cf_l[in.er];
   T Y[N];
-#if defined(FUS_ABLATE) && FUS_ABLATE == 1  // timing experiment: loads only, no contractions
-  if (OP == OP_STIFFNESS && GEOM == GEOM_STREAM)
-  {
-#pragma unroll
-    for (int a = 0; a < N; ++a)
-    {
-      T acc = x_l[li[a]];
-#pragma unroll
-      for (int gi = 0; gi < 6; ++gi)
-      {
-        const int v = gi * N + a;
-        acc += in.g[v / VW][v % VW];
-      }
-      Y[a] = acc * cf;
-    }
-  }
-  else
-#endif
   if (OP == OP_STIFFNESS)
   {
     T X[N], F0[N], F1[N], F2[N];
@@ -940,11 +913,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
       }
 #pragma unroll
     for (int u = 0; u < US; ++u)
-#if defined(FUS_ABLATE) && FUS_ABLATE == 3  // timing experiment: shared-dof values from a contiguous range, no index list
-      gi[u] = int_off + ((tid + u * nthr < sh.nint) ? tid + u * nthr : 0);
-#else
       gi[u] = (tid + u * nthr < nsh) ? gix[tid + u * nthr] : 0;
-#endif
 #pragma unroll
     for (int u = 0; u < UL; ++u)
       if (tid + u * nthr < n16)
@@ -995,6 +964,17 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
       w_l[tid - N2] = dgv;
     if (GCS && tid >= N2 + N && tid < N2 + 2 * N)
       pt_l[tid - N2 - N] = dgv;
+    // (a one-wave workgroup at the higher degrees has fewer threads than table entries)
+    for (int k = tid + nthr; k < N2 + 2 * N; k += nthr)
+    {
+      const T v = Dg[k];
+      if (k < N2)
+        D_l[k] = v;
+      else if (GCS && k < N2 + N)
+        w_l[k - N2] = v;
+      else if (GCS)
+        pt_l[k - N2 - N] = v;
+    }
     if (tid == 0 && (sh.nint & 1))
     {
       x_l[sh.nint - 1] = xtail;
@@ -1367,12 +1347,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   }
   for (int l = sh.nint + tid; l < sh.nloc; l += nthr)
     partial[sh_off + (l - sh.nint)] = y_l[l];
-#ifdef FUS_TRACE
-  __syncthreads();
-  FUS_STAMP(blk, 3);
-  if (threadIdx.x == 0 && blk < 65536)
-    g_fus_trace[(size_t)blk * 8 + 4] = __smid();
-#endif
+  FUS_TRACE_END(blk);
 }
 
 // bsh[s] = sum over the (block, slot) pairs of shared dof s, ascending block order (a trailing

@@ -1,8 +1,10 @@
-"""Bridge from real DOLFINx objects to the inputs libfusmi takes.
+"""Bridge from DOLFINx objects to the inputs libfusmi takes.
 
-DOLFINx/Basix are not installed where this repository is built and tested, so this module is
-import-guarded and NOT exercised by the test-suite; it restates, call for call, what the
-reference does with the same objects:
+DOLFINx/Basix are not installed where this repository is built and tested, so the module imports
+them lazily; its logic is exercised by tests/test_dolfinx_adapter.py with duck-typed stand-ins for
+the handful of attributes it reads (``V.dofmap.list``, ``V.dofmap.index_map.{size_local, num_ghosts,
+size_global, local_range, ghosts, owners, index_to_dest_ranks()}``, ``basix.tp_dof_ordering``,
+``basix.make_quadrature``).  It restates, call for call, what the reference does with the same objects:
 
 * tensor-product dofmap: ``reorder_dofmap`` (cpp/fenicsx-sf/common/permute.hpp:15-42) --
   ``perm = argsort(basix.tp_dof_ordering(P, hexahedron, gll_warped))`` and
@@ -14,7 +16,12 @@ reference does with the same objects:
   ``fem::compute_integration_domains(exterior_facet, topology, ft->find(tag), tdim-1)`` returns
   (cpp/fenicsx-sf/common/Linear.hpp:113-118);
 * shared DOFs per neighbour rank from the function space's ``IndexMap`` (the data behind
-  ``la::Vector::scatter_fwd/scatter_rev``, Linear.hpp:196-206).
+  ``la::Vector::scatter_fwd/scatter_rev``, Linear.hpp:196-206).  The library's exchange is
+  symmetric -- every rank that holds a DOF adds the partial sums of ALL the other holders, in
+  ascending rank order -- while an ``IndexMap`` only links a ghost to its owner: two ranks that both
+  ghost a DOF owned by a third (partition edges and corners) do not know of each other.  The owner
+  therefore tells every ghosting rank which other ranks hold the DOF (one all-to-all at setup,
+  :func:`sharer_messages` / :func:`neighbours_from_index_map`).
 
 Usage where DOLFINx exists::
 
@@ -23,6 +30,7 @@ Usage where DOLFINx exists::
     tags = wrap_facet_tags(mesh, mt_facet)
     model = LinearSpectralExplicit(mesh, tags, degree, c0, rho0, f0, p0, s0, 4, dt, V=V)
     u_n, v_n, t = model.rk(t0, tf)            # u_n.x.array is in DOLFINx's own DOF numbering
+    copy_to_function(u_n, dolfinx_u)          # ... so VTXWriter / post-processing keep working
 """
 from __future__ import annotations
 
@@ -59,42 +67,76 @@ class _WrappedSpace:
         return im.size_local + im.num_ghosts
 
 
-def wrap_function_space(V, P: int):
-    """``V``: a ``dolfinx.fem.FunctionSpace`` of degree-P ``gll_warped`` Lagrange on hexahedra or
-    quadrilaterals."""
-    basix, dolfinx = _require()
+def tensor_dofmap_of(V, P: int, basix):
+    """``reorder_dofmap`` (permute.hpp:15-42): the cell dofmap of the locally owned cells with every row
+    permuted by ``argsort(tp_dof_ordering)``."""
     cell = basix.CellType.hexahedron if V.mesh.topology.dim == 3 else basix.CellType.quadrilateral
     tp_order = np.asarray(basix.tp_dof_ordering(basix.ElementFamily.P, cell, P,
                                                 basix.LagrangeVariant.gll_warped, basix.DPCVariant.unset, False))
     perm = np.argsort(tp_order, kind="stable")                    # permute.hpp:27-32
     dm = np.asarray(V.dofmap.list).reshape(-1, len(tp_order))
     ncells = V.mesh.topology.index_map(V.mesh.topology.dim).size_local
-    tensor_dofmap = np.ascontiguousarray(dm[:ncells][:, perm], dtype=np.int32)   # permute.hpp:38-41
+    return np.ascontiguousarray(dm[:ncells][:, perm], dtype=np.int32)   # permute.hpp:38-41
+
+
+def wrap_function_space(V, P: int, basix=None, alltoall=None):
+    """``V``: a ``dolfinx.fem.FunctionSpace`` of degree-P ``gll_warped`` Lagrange on hexahedra or
+    quadrilaterals.  ``alltoall(send: dict rank -> int64 array) -> dict rank -> int64 array`` moves the
+    sharer messages between the ranks (default: ``mesh.comm`` through mpi4py)."""
+    if basix is None:
+        basix, _ = _require()
+    tensor_dofmap = tensor_dofmap_of(V, P, basix)
     pts, _ = basix.make_quadrature(basix.CellType.interval, QDEGREE[P], basix.QuadratureType.gll)
     nodes1d = np.ascontiguousarray(np.asarray(pts).reshape(-1), dtype=np.float64)
-    return _WrappedSpace(V, P, tensor_dofmap, nodes1d, _neighbours(V))
+    return _WrappedSpace(V, P, tensor_dofmap, nodes1d, _neighbours(V, alltoall))
 
 
-def _neighbours(V):
-    """(rank, local dof indices) per neighbour rank, each list ordered by global index so both sides
-    agree: ghosts owned by rank r are shared with r; owned dofs that are ghosts elsewhere are
-    found through the index map's shared-index data."""
-    im = V.dofmap.index_map
-    if im.num_ghosts == 0 and im.size_global == im.size_local:
-        return []
-    n_owned = im.size_local
-    shared = {}
-    owners = np.asarray(im.owners)
-    ghosts = np.asarray(im.ghosts)
-    for k, (g, r) in enumerate(zip(ghosts, owners)):            # my ghosts: shared with their owner
-        shared.setdefault(int(r), []).append((int(g), n_owned + k))
-    # my owned dofs that other ranks ghost: index_to_dest_ranks gives, per owned index, the ranks
+def _dest_ranks(im):
     dest = im.index_to_dest_ranks()
-    offs, ranks = np.asarray(dest.offsets), np.asarray(dest.array)
-    lo = im.local_range[0]
-    for i in range(n_owned):
+    return np.asarray(dest.offsets), np.asarray(dest.array)
+
+
+def sharer_messages(im):
+    """Owner side.  For every owned DOF that two or more other ranks ghost, the message to each of those
+    ranks r: (global index, k, the k other ghosting ranks besides r).  Returns {rank: int64 array}."""
+    offs, ranks = _dest_ranks(im)
+    lo = int(im.local_range[0])
+    cnt = np.diff(offs[:im.size_local + 1])
+    out = {}
+    for i in np.nonzero(cnt >= 2)[0]:
+        R = [int(r) for r in ranks[offs[i]:offs[i + 1]]]
+        for r in R:
+            out.setdefault(r, []).extend([lo + int(i), len(R) - 1, *[q for q in R if q != r]])
+    return {r: np.asarray(v, dtype=np.int64) for r, v in out.items()}
+
+
+def neighbours_from_index_map(im, received):
+    """(rank, local dof indices) per neighbour rank with EVERY pair of holders of a DOF listing each
+    other, each list ordered by global index so that both sides agree.  ``received``: the other
+    ranks' :func:`sharer_messages` addressed to this rank, {source rank: int64 array}."""
+    n_owned = int(im.size_local)
+    lo = int(im.local_range[0])
+    owners = np.asarray(im.owners).astype(np.int64)
+    ghosts = np.asarray(im.ghosts).astype(np.int64)
+    shared = {}                                                   # rank -> [(global, local)]
+    for k in range(len(ghosts)):                                  # my ghosts: held by their owner
+        shared.setdefault(int(owners[k]), []).append((int(ghosts[k]), n_owned + k))
+    offs, ranks = _dest_ranks(im)                                 # my owned dofs that other ranks ghost
+    cnt = np.diff(offs[:n_owned + 1])
+    for i in np.nonzero(cnt > 0)[0]:
         for r in ranks[offs[i]:offs[i + 1]]:
-            shared.setdefault(int(r), []).append((lo + i, i))
+            shared.setdefault(int(r), []).append((lo + int(i), int(i)))
+    ghost_local = {int(g): n_owned + k for k, g in enumerate(ghosts)}
+    for src, msg in received.items():                             # the other holders of my ghosts
+        msg = np.asarray(msg, dtype=np.int64)
+        p = 0
+        while p < len(msg):
+            g, k = int(msg[p]), int(msg[p + 1])
+            if g not in ghost_local:
+                raise ValueError(f"rank {src} names global dof {g}, which is not a ghost here")
+            for q in msg[p + 2:p + 2 + k]:
+                shared.setdefault(int(q), []).append((g, ghost_local[g]))
+            p += 2 + k
     out = []
     for r in sorted(shared):
         pairs = sorted(set(shared[r]))
@@ -102,10 +144,33 @@ def _neighbours(V):
     return out
 
 
+def _mpi_alltoall(comm):
+    def alltoall(send):
+        size = comm.Get_size()
+        got = comm.alltoall([send.get(r, np.zeros(0, np.int64)) for r in range(size)])
+        return {r: m for r, m in enumerate(got) if len(m)}
+    return alltoall
+
+
+def _neighbours(V, alltoall=None):
+    im = V.dofmap.index_map
+    if im.num_ghosts == 0 and im.size_global == im.size_local:
+        return []
+    if alltoall is None:
+        alltoall = _mpi_alltoall(V.mesh.comm)
+    return neighbours_from_index_map(im, alltoall(sharer_messages(im)))
+
+
+def copy_to_function(src, dst):
+    """Model output (``.x.array`` in DOLFINx's DOF numbering, owned + ghosts) -> a ``dolfinx.fem.Function``."""
+    dst.x.array[:] = np.asarray(src.x.array, dtype=dst.x.array.dtype)
+    return dst
+
+
 def wrap_facet_tags(mesh, meshtags):
     """DOLFINx ``MeshTags`` on facets -> object with ``cells``, ``local_facets``, ``values``
     ((cell, local facet) pairs of the tagged exterior facets, Linear.hpp:113-118)."""
-    basix, dolfinx = _require()
+    _require()
     from dolfinx import fem
 
     tdim = mesh.topology.dim

@@ -141,9 +141,11 @@ class _SpectralExplicit:
         return out
 
     def close(self):
+        """Frees the model and the operator data it created (G, dofmaps, partial slab)."""
         if self.h:
             lib().fus_model_destroy(self.h)
             self.h = C.c_void_p()
+        self.data.close()
 
 
 class LinearSpectralExplicit(_SpectralExplicit):

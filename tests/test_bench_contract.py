@@ -27,7 +27,8 @@ def test_bench_refuses_to_run_without_gpu():
 
 @pytest.mark.gpu
 def test_bench_json_contract():
-    out = run_bench("--steps", "3", "--warmup", "1", "--cells", "16", "--cpu-n", "8", "--cpu-steps", "5")
+    out = run_bench("--steps", "3", "--warmup", "1", "--repeats", "3", "--cells", "16", "--cpu-n", "8", "--cpu-steps", "5",
+                    "--traffic", "profile")
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1                      # exactly one line on stdout, everything else on stderr
@@ -45,7 +46,9 @@ def test_bench_json_contract():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
-    assert r["traffic"] is None                 # PMC traffic is only quoted for the profiled configuration
+    assert r["traffic"] is None and r["frac_real"] is None   # no committed PMC passes for this small configuration
+    rp = d["repeats"]
+    assert rp["n"] == 3 and len(rp["ms_per_step"]) == 3 and rp["min"] <= d["ms_per_step"] <= rp["max"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "DOF-updates/s" and c["sample"]
     # the other geometry paths are timed beside the headline at N = 1

@@ -47,6 +47,24 @@ def test_operators_vs_oracle(orc, P, det):
     d.close()
 
 
+@pytest.mark.parametrize("P", [5, 7])
+@pytest.mark.parametrize("geometry,perturb", [("trilinear", 0.2), (None, 0.0)])
+def test_one_wave_workgroups_high_degree(orc, P, geometry, perturb):
+    """Option waves = 1 at the higher degrees: a 64-thread workgroup has fewer threads than the prologue
+    has table entries (N^2 + 2 N = 80 at degree 7), which the per-cell geometry kernels read their
+    quadrature weights and points from."""
+    pr = Problem(orc, (3, 2, 2), P, hi=[1.5, 1.0, 0.8], perturb=perturb)
+    c = fa.Context(0, geometry=geometry, waves=1)
+    d = fa.SpectralOperatorData(pr.V, c)
+    assert d.geometry_mode() == ("trilinear" if perturb else "affine")
+    rng = np.random.default_rng(P)
+    x, coef = rng.standard_normal(pr.ndofs), rng.uniform(0.5, 2.0, pr.mesh.num_cells)
+    assert relmax(d.stiffness(x, coef, np.zeros(pr.ndofs)), pr.K(x, coef)) < TOL_OP
+    assert relmax(d.mass(x, coef, np.zeros(pr.ndofs)), pr.M(x, coef)) < 1e-13
+    d.close()
+    c.close()
+
+
 def test_far_from_origin_and_small_cells(orc, ctx):
     # millimetre cells a metre away from the origin: the map coefficients are differences of vertex
     # coordinates, so the accuracy must follow the cell size, not the coordinate magnitude

@@ -257,6 +257,13 @@ def main():
                          "does by default on any first-order hexahedral mesh with non-affine cells, taken here without "
                          "the affine shortcut the synthetic box would allow; stream: per-point G from HBM (the reference's "
                          "data path); auto: the library default (this box is affine: 7 numbers per cell)")
+    ap.add_argument("--mfma", type=int, default=None, choices=[-1, 0, 1],
+                    help="degrees 6 and 7: index-1 / index-2 contractions on the matrix cores (1), on the vector ALUs (0), "
+                         "or the library's measured default (-1)")
+    ap.add_argument("--walk", type=int, default=None,
+                    help="block-kernel workgroups per CU that walk several blocks each (0: one workgroup per block)")
+    ap.add_argument("--lean-rk4", type=int, default=None, choices=[0, 1],
+                    help="0: keep the RK4 accumulators u_, v_ in HBM at every stage (Linear.hpp:282-294); default 1")
     ap.add_argument("--graph", type=int, default=None, help="1: replay each RK step as one hipGraph (launch-bound sizes)")
     ap.add_argument("--both-geometries", type=int, default=1,
                     help="1: at N=1 also time the other two geometry paths -> 'other_geometry' (affine), 'trilinear_geometry', "
@@ -311,7 +318,8 @@ def main():
                 "--medium", args.medium]
         if args.global_cells:
             tail += ["--global-cells", str(args.global_cells)]
-        for k, v in (("--block-elems", args.block_elems), ("--waves", args.waves), ("--deterministic", args.deterministic)):
+        for k, v in (("--block-elems", args.block_elems), ("--waves", args.waves), ("--deterministic", args.deterministic),
+                     ("--mfma", args.mfma), ("--lean-rk4", args.lean_rk4), ("--walk", args.walk)):
             if v is not None:
                 tail += [k, str(v)]
         traffic, traffic_src = live_traffic(tail, args.P, args.dtype)
@@ -329,6 +337,9 @@ def main():
     ctx = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves, deterministic=args.deterministic, geometry=args.geometry)
     if args.graph is not None:
         ctx.set_option("graph", args.graph)
+    for key, val in (("mfma", args.mfma), ("lean_rk4", args.lean_rk4), ("walk", args.walk)):
+        if val is not None:
+            ctx.set_option(key, val)
     transport = args.transport
     if args.halo_loopback:
         assert world == 1 and not launched
@@ -410,6 +421,7 @@ def main():
                 model.rk4_steps(t, dt, n, sync=False)
         model.init()
         info = model.data.info()
+        info["mfma"] = model.data.uses_mfma()
         affine = model.data.geometry_mode()        # "stream" | "affine" | "trilinear"
         advance(0.0, warmup)
         done = warmup
@@ -463,6 +475,7 @@ def main():
     times, prof, info, affine, finite = run(ctx, args.steps, args.warmup, max(1, args.repeats), not args.no_profile,
                                             headline=True)
     elapsed = float(np.median(times))
+    mfma_used = bool(info.get("mfma"))
     if args.no_profile:
         prof = {"stiffness": (0.0, 0), "stiffness_if": (0.0, 0), "breakdown_ms_per_step": {}}
     # secondary measurements: the same workload through the other geometry paths ("auto": the box
@@ -546,7 +559,7 @@ def main():
                        "medium": args.medium,
                        "partition": "middle x-slab of 3, exchange looped back (diagnostic)" if args.halo_loopback
                        else f"x-slabs x{world}", "transport": transport if (world > 1 or args.halo_loopback) else "none",
-                       "blocks": info["nblocks"],
+                       "blocks": info["nblocks"], "mfma_contractions": mfma_used,
                        "lds_bytes_per_block": info["lds_bytes"], "dt": dt},
             # the timed K-step block repeated: value / ms_per_step are the median repeat
             "repeats": {"n": len(times), "ms_per_step": ms_rep, "min": min(ms_rep), "max": max(ms_rep),

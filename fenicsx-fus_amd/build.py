@@ -20,8 +20,8 @@ DEGREES = (2, 3, 4, 5, 6, 7)
 
 
 def _compile_units(objdir, degrees, extra, verbose):
-    """fusmi.hip is compiled once per polynomial degree (-DFUS_TU_DEGREE=k: the block kernels of
-    that degree) and once as the main unit (C ABI + degree-independent code), concurrently."""
+    """fusmi.hip is compiled once per polynomial degree and scalar type (-DFUS_TU_DEGREE=k -DFUS_TU_DTYPE=64|32:
+    the block kernels of that degree) and once as the main unit (C ABI + degree-independent code), concurrently."""
     from concurrent.futures import ThreadPoolExecutor
 
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -30,8 +30,9 @@ def _compile_units(objdir, degrees, extra, verbose):
     jobs = [([hipcc, *FLAGS, *extra, "-c", SRC[0], "-o", os.path.join(objdir, "fusmi_main.o")]),
             ([hipcc, *FLAGS, *extra, "-c", SRC[1], "-o", os.path.join(objdir, "layout.o")])]
     for k in degrees:
-        jobs.append([hipcc, *FLAGS, *extra, f"-DFUS_TU_DEGREE={k}", "-c", SRC[0], "-o",
-                     os.path.join(objdir, f"fusmi_p{k}.o")])
+        for bits in (64, 32):
+            jobs.append([hipcc, *FLAGS, *extra, f"-DFUS_TU_DEGREE={k}", f"-DFUS_TU_DTYPE={bits}", "-c", SRC[0], "-o",
+                         os.path.join(objdir, f"fusmi_p{k}_f{bits}.o")])
 
     def run(cmd):
         if verbose:

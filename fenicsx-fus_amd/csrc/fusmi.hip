@@ -168,6 +168,14 @@ struct fus_ctx
   // package (python/src/fenicsxfus/_lossy.py:107-128, :186-189: those terms on tag 2 only, source
   // not doubled)
   int forms = 0;
+  // classical RK4 without the redundant accumulator streams (stage kinds 4-6, kernels.hpp): 1 (default);
+  // 0 keeps u_, v_ in HBM at every stage like Linear.hpp:282-294
+  int lean_rk4 = 1;
+  // index-1 / index-2 contractions of the degrees 6 and 7 on the matrix cores (per-cell geometry kernels):
+  // -1 auto (the measured choice per degree, scalar type and geometry), 0 never, 1 wherever a variant exists
+  int mfma = -1;
+  int walk = -1;  // block-kernel workgroups per CU that walk several blocks each (0: one workgroup per block,
+                  // -1: auto), see launch_block_op_v
 };
 
 struct Neigh
@@ -202,6 +210,7 @@ struct fus_op
   int nfields = 1;
   bool affine = false;     // GEOM_AFFINE path in use (d_Gc), streamed G/detJ built only on demand
   bool trilinear = false;  // GEOM_TRILINEAR path in use (d_Gc holds 21 map coefficients per cell)
+  bool mfma = false;       // MFMA contraction variants of the block kernel in use (degrees 6, 7)
   void* d_Gc = nullptr;
   void *d_xg = nullptr, *d_pts = nullptr, *d_wts = nullptr;
   int32_t* d_xdm = nullptr;
@@ -242,6 +251,7 @@ struct fus_model
   bool setup_done = false;
   int rk_order = 4;  // explicit Runge-Kutta scheme, tables of python/src/fenicsxfus/_linear.py:286-311
   int forms = 0;     // fus_ctx::forms at creation
+  int lean_rk4 = 1;  // fus_ctx::lean_rk4 at creation
   // The boundary term of the shared boundary dofs rides in pseudo partial slots.  With RK4 the
   // shared-dof stage kernels write the NEXT stage's values there (boundary_next, kernels.hpp);
   // bnd_valid / bnd_tn say for which stage time the slots are current, and stage_begin launches
@@ -311,34 +321,60 @@ struct ProfScope
 // -------------------------------------------------------------------------------------------------
 // typed implementation
 // -------------------------------------------------------------------------------------------------
-template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3>
+template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3, int MF = 0>
 static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec,
                              const StageArgs<T>& S, int blk_begin, int blk_count)
 {
   if (blk_count <= 0)
     return FUS_OK;
   constexpr int N = P + 1;
-  DTab<T, N> Dk;
+  KArgs<T, N> K;
   for (int i = 0; i < N * N; ++i)
-    Dk.d[i] = (T)op->D[i];
+    K.Dk.d[i] = (T)op->D[i];
   for (int i = 0; i < N; ++i)
-    Dk.w[i] = (T)op->wts[i], Dk.x[i] = (T)op->nodes[i];
+    K.Dk.w[i] = (T)op->wts[i], K.Dk.x[i] = (T)op->nodes[i];
   // the attribute is per device: one bit per device and instantiation (set again harmlessly if two
   // threads race on the first launch)
   static std::atomic<uint64_t> attr_set{0};
   const uint64_t dev_bit = 1ull << (op->ctx->device & 63);
   if (!(attr_set.load(std::memory_order_relaxed) & dev_bit))
   {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD, MF>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
   }
-  BlockArgs A = op->A;
-  A.blk_begin = blk_begin;
-  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD>), dim3(blk_count),
-                     dim3(64 * op->L.waves), op->lds_bytes, op->ctx->stream, A, Dk,
-                     static_cast<const T*>(op->d_Dg), geo, coef, x, bvec,
-                     static_cast<T*>(op->d_partial), S);
+  K.A = op->A;
+  K.A.blk_begin = blk_begin;
+  K.A.blk_count = blk_count;
+  K.Dg = static_cast<const T*>(op->d_Dg), K.geo = geo, K.coef = coef, K.x = x, K.bvec = bvec;
+  K.partial = static_cast<T*>(op->d_partial);
+  K.S = S;
+  // option "walk" = w > 0: w workgroups per CU, each walking every (w * CUs)-th block of the range with
+  // the next block's prologue loads in flight under the current block's epilogue (per-cell geometry
+  // kernels; the streamed-geometry kernel keeps one workgroup per block)
+  int grid = blk_count;
+  if (GEOM != GEOM_STREAM && TD == 3 && op->ctx->walk != 0)
+  {
+    int per_cu = op->ctx->walk;
+    if (per_cu < 0)  // auto: as many workgroups per CU as are resident at once (measured best: 2 eight-wave /
+    {                // 4 four-wave blocks at degree 4), where a workgroup then has at least 4 blocks to walk
+      static int occ[2] = {-1, -1};  // per instantiation; [0]: this LDS size
+      static size_t occ_lds = 0;
+      if (occ[0] < 0 || occ_lds != op->lds_bytes)
+      {
+        int nb = 0;
+        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+            &nb, reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD, MF>), 64 * op->L.waves,
+            op->lds_bytes));
+        occ[0] = std::max(nb, 1), occ_lds = op->lds_bytes;
+      }
+      per_cu = (P == 4 && sizeof(T) == 8 && blk_count >= 4 * occ[0] * op->ctx->num_cus) ? occ[0] : 0;
+    }
+    if (per_cu > 0)
+      grid = std::min(blk_count, per_cu * op->ctx->num_cus);
+  }
+  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD, MF>), dim3(grid),
+                     dim3(64 * op->L.waves), op->lds_bytes, op->ctx->stream, K);
   HIPCHK(hipGetLastError());
   return FUS_OK;
 }
@@ -357,6 +393,18 @@ static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, 
     return op->deterministic
                ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_STREAM, 2>(op, geo, coef, x, bvec, S, b0, nb)
                : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_STREAM, 2>(op, geo, coef, x, bvec, S, b0, nb);
+  // degrees 6 and 7, per-cell geometry, LDS-atomic accumulation: the index-1 / index-2 contractions on the
+  // matrix cores (kernels.hpp, elem_compute_mfma) where option "mfma" / the measured default says so; the
+  // variants exist for the stiffness operator as the plain action and as the lean RK4 stages
+  if constexpr (P >= 6 && OP == OP_STIFFNESS && (STAGE == STAGE_NONE || STAGE >= 3))
+  {
+    if (op->mfma && !op->deterministic && op->tdim == 3 && (op->affine || op->trilinear))
+    {
+      const T* gc = static_cast<const T*>(op->d_Gc);
+      return op->affine ? launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_AFFINE, 3, 1>(op, gc, coef, x, bvec, S, b0, nb)
+                        : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_TRILINEAR, 3, 1>(op, gc, coef, x, bvec, S, b0, nb);
+    }
+  }
   // geometry operand: per-cell factors (affine meshes) or the streamed per-point arrays
   if (op->affine)
   {
@@ -543,6 +591,14 @@ static int ensure_stream_geometry(fus_op* op)
   return FUS_OK;
 }
 
+// Measured choice (MI355X, profiles/r02_mfma.md) between the vector and the matrix-core form of the
+// index-1 / index-2 contractions.
+static bool mfma_default(int P, bool f64, bool affine)
+{
+  (void)P, (void)f64, (void)affine;
+  return false;
+}
+
 template <typename T, int P>
 static int op_setup_device(fus_op* op)
 {
@@ -630,6 +686,10 @@ static int op_setup_device(fus_op* op)
   op->d_Gc = d_Gc;
   op->affine = c->geometry == 0 && rel_err <= (sizeof(T) == 8 ? 1e-12f : 1e-6f);
   op->trilinear = !op->affine && c->geometry != 1 && op->geom_order == 1 && op->tdim == 3;
+  // matrix-core contraction variants: degrees 6 and 7 on the per-cell geometry paths; "auto" follows the
+  // A/B measurements on MI355X (profiles/r02_mfma.md)
+  op->mfma = (P == 6 || P == 7) && (op->affine || op->trilinear) && !op->deterministic
+             && (c->mfma == 1 || (c->mfma < 0 && mfma_default(P, sizeof(T) == 8, op->affine)));
   if (op->affine)
     op->lds_bytes = L.lds_bytes(sizeof(T), op->nfields, 7);
   else if (op->trilinear)
@@ -996,6 +1056,7 @@ static int model_setup_finish(fus_model* m)
 struct StageScalars
 {
   double gval, dgval, adt, bdt;
+  double b0dt, r0, r1;  // dt b_0, b_0 / a_1, b_1 / a_2 (lean RK4 stage kinds)
   double tn;  // the stage's time t + c_i dt as the scalars above saw it (in T)
 };
 
@@ -1054,6 +1115,9 @@ static StageScalars stage_scalars(const fus_model* m, int i, double t_, double d
   }
   sc.adt = (double)(dt * a_runge[i + 1]);
   sc.bdt = (double)(dt * b_runge[i]);
+  sc.b0dt = (double)(dt * b_runge[0]);
+  sc.r0 = a_runge[1] != T(0) ? (double)(b_runge[0] / a_runge[1]) : 0.0;
+  sc.r1 = a_runge[2] != T(0) ? (double)(b_runge[1] / a_runge[2]) : 0.0;
   sc.tn = (double)tn;
   return sc;
 }
@@ -1063,6 +1127,8 @@ static StageScalars stage_scalars(const fus_model* m, int i, double t_, double d
 // stage and swap (u_, v_) with (u0, v0) afterwards.
 static int stage_kind(const fus_model* m, int i)
 {
+  if (m->rk_order == 4 && m->lean_rk4)   // classical RK4 without the redundant accumulator streams
+    return i == 3 ? 3 : 4 + i;
   if (i == 0)
     return 0;
   return (m->rk_order == 4 && i == 3) ? 3 : 1;
@@ -1077,6 +1143,7 @@ static StageArgs<T> stage_args(fus_model* m, const StageScalars& sc)
   S.u0 = static_cast<T*>(m->u0), S.v0 = static_cast<T*>(m->v0);
   S.u_ = static_cast<T*>(m->u_), S.v_ = static_cast<T*>(m->v_);
   S.adt = (T)sc.adt, S.bdt = (T)sc.bdt, S.gval = (T)sc.gval;
+  S.b0dt = (T)sc.b0dt, S.r0 = (T)sc.r0, S.r1 = (T)sc.r1;
   S.blk_bnd_off = m->d_blk_bnd_off, S.bnd_idx = m->d_bidx;
   S.bnd_src = static_cast<const T*>(m->d_bsrc), S.bnd_abs = static_cast<const T*>(m->d_babs);
   S.x2 = nullptr, S.coef2 = static_cast<const T*>(m->coef2);
@@ -1101,19 +1168,25 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
   const int kind = stage_kind(m, i);
   auto launch = [&](int b0, int nb) -> int
   {
+#define FUS_STAGE_CASE(K, NFV)                                                                       \
+  case K:                                                                                          \
+    return launch_block_op<T, P, OP_STIFFNESS, K, NFV>(op, G, coef, ustage, b, S, b0, nb);
     if (m->kind == FUS_LOSSY || m->kind == FUS_WESTERVELT)
     {
-      if (kind == 0)
-        return launch_block_op<T, P, OP_STIFFNESS, 0, 2>(op, G, coef, ustage, b, S, b0, nb);
-      if (kind == 3)
-        return launch_block_op<T, P, OP_STIFFNESS, 3, 2>(op, G, coef, ustage, b, S, b0, nb);
-      return launch_block_op<T, P, OP_STIFFNESS, 1, 2>(op, G, coef, ustage, b, S, b0, nb);
+      switch (kind)
+      {
+        FUS_STAGE_CASE(0, 2) FUS_STAGE_CASE(3, 2) FUS_STAGE_CASE(4, 2) FUS_STAGE_CASE(5, 2) FUS_STAGE_CASE(6, 2)
+      default:
+        return launch_block_op<T, P, OP_STIFFNESS, 1, 2>(op, G, coef, ustage, b, S, b0, nb);
+      }
     }
-    if (kind == 0)
-      return launch_block_op<T, P, OP_STIFFNESS, 0>(op, G, coef, ustage, b, S, b0, nb);
-    if (kind == 3)
-      return launch_block_op<T, P, OP_STIFFNESS, 3>(op, G, coef, ustage, b, S, b0, nb);
-    return launch_block_op<T, P, OP_STIFFNESS, 1>(op, G, coef, ustage, b, S, b0, nb);
+    switch (kind)
+    {
+      FUS_STAGE_CASE(0, 1) FUS_STAGE_CASE(3, 1) FUS_STAGE_CASE(4, 1) FUS_STAGE_CASE(5, 1) FUS_STAGE_CASE(6, 1)
+    default:
+      return launch_block_op<T, P, OP_STIFFNESS, 1>(op, G, coef, ustage, b, S, b0, nb);
+    }
+#undef FUS_STAGE_CASE
   };
   // Multi-rank, option "overlap_blocks": the blocks that touch interface dofs (first in the layout)
   // run ahead, their partials are reduced, packed and handed to the exchange, and the remaining
@@ -1200,27 +1273,27 @@ static int stage_end(fus_model* m, int i, double t, double dt)
     m->bnd_valid = true, m->bnd_tn = scn.tn;
     op->bnd_owner = m;
   }
+  const LeanRK<T> R{(T)sc.b0dt, (T)sc.r0, (T)sc.r1};
+  const int kind = stage_kind(m, i);
   if (nloc > 0)
   {
     ProfScope ps(c, "stage");
     const dim3 grid(nblk(nloc)), blk(256);
-    switch (stage_kind(m, i))
+#define FUS_SHARED_CASE(K)                                                                         \
+  case K:                                                                                          \
+    hipLaunchKernelGGL((k_shared_stage<T, K>), grid, blk, 0, st, nloc, m->d_sh_ptr32, m->d_sh_pairs32, partial,      \
+                       minv + off, vn + off, un + off, u0 + off, v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p, B, \
+                       R);                                                                         \
+    break;
+    switch (kind)
     {
-    case 0:
-      hipLaunchKernelGGL((k_shared_stage<T, 0>), grid, blk, 0, st, nloc, m->d_sh_ptr32,
-                         m->d_sh_pairs32, partial, minv + off, vn + off, un + off, u0 + off,
-                         v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p, B);
-      break;
-    case 3:
-      hipLaunchKernelGGL((k_shared_stage<T, 3>), grid, blk, 0, st, nloc, m->d_sh_ptr32,
-                         m->d_sh_pairs32, partial, minv + off, vn + off, un + off, u0 + off,
-                         v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p, B);
-      break;
+      FUS_SHARED_CASE(0) FUS_SHARED_CASE(3) FUS_SHARED_CASE(4) FUS_SHARED_CASE(5) FUS_SHARED_CASE(6)
     default:
-      hipLaunchKernelGGL((k_shared_stage<T, 1>), grid, blk, 0, st, nloc, m->d_sh_ptr32,
-                         m->d_sh_pairs32, partial, minv + off, vn + off, un + off, u0 + off,
-                         v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p, B);
+      hipLaunchKernelGGL((k_shared_stage<T, 1>), grid, blk, 0, st, nloc, m->d_sh_ptr32, m->d_sh_pairs32, partial,
+                         minv + off, vn + off, un + off, u0 + off, v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p, B,
+                         R);
     }
+#undef FUS_SHARED_CASE
   }
   if (!op->neigh.empty())
   {
@@ -1233,23 +1306,21 @@ static int stage_end(fus_model* m, int i, double t, double dt)
     const T* recv = static_cast<const T*>(op->d_recvbuf);
     const T* m0f = m->mn1 ? static_cast<const T*>(m->m) : nullptr;
     const T* mn1f = m->mn1 ? static_cast<const T*>(m->mn1) : nullptr;
-    switch (stage_kind(m, i))
+#define FUS_IF_CASE(K)                                                                             \
+  case K:                                                                                          \
+    hipLaunchKernelGGL((k_if_unpack_stage<T, K>), grid, blk, 0, st, op->n_uidx, op->d_uidx, op->d_uptr, op->d_usrc,  \
+                       recv, b, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0f, mn1f, op->L.n_int_pad, m->d_sh_ptr32,    \
+                       m->d_sh_pairs32, B, R);                                                     \
+    break;
+    switch (kind)
     {
-    case 0:
-      hipLaunchKernelGGL((k_if_unpack_stage<T, 0>), grid, blk, 0, st, op->n_uidx, op->d_uidx,
-                         op->d_uptr, op->d_usrc, recv, b, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0f,
-                         mn1f, op->L.n_int_pad, m->d_sh_ptr32, m->d_sh_pairs32, B);
-      break;
-    case 3:
-      hipLaunchKernelGGL((k_if_unpack_stage<T, 3>), grid, blk, 0, st, op->n_uidx, op->d_uidx,
-                         op->d_uptr, op->d_usrc, recv, b, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0f,
-                         mn1f, op->L.n_int_pad, m->d_sh_ptr32, m->d_sh_pairs32, B);
-      break;
+      FUS_IF_CASE(0) FUS_IF_CASE(3) FUS_IF_CASE(4) FUS_IF_CASE(5) FUS_IF_CASE(6)
     default:
-      hipLaunchKernelGGL((k_if_unpack_stage<T, 1>), grid, blk, 0, st, op->n_uidx, op->d_uidx,
-                         op->d_uptr, op->d_usrc, recv, b, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0f,
-                         mn1f, op->L.n_int_pad, m->d_sh_ptr32, m->d_sh_pairs32, B);
+      hipLaunchKernelGGL((k_if_unpack_stage<T, 1>), grid, blk, 0, st, op->n_uidx, op->d_uidx, op->d_uptr, op->d_usrc,
+                         recv, b, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0f, mn1f, op->L.n_int_pad, m->d_sh_ptr32,
+                         m->d_sh_pairs32, B, R);
     }
+#undef FUS_IF_CASE
   }
   HIPCHK(hipGetLastError());
   return FUS_OK;
@@ -1335,39 +1406,47 @@ static DegreeImpl make_degree_impl()
   return {&op_setup_device<T, P>, &op_apply_kind<T, P>, &op_get_geometry<T, P>,
           &model_setup<T, P>,     &model_step<T, P>,    &stage_begin<T, P>};
 }
-FUS_HIDDEN const DegreeImpl* FUS_CAT(fus_degree_impl_, FUS_TU_DEGREE)(int dtype)
+// one unit per (degree, scalar type): -DFUS_TU_DEGREE=k -DFUS_TU_DTYPE=64|32
+#if FUS_TU_DTYPE == 64
+FUS_HIDDEN const DegreeImpl* FUS_CAT(FUS_CAT(fus_degree_impl_, FUS_TU_DEGREE), _f64)()
 {
-  static const DegreeImpl f64 = make_degree_impl<double, FUS_TU_DEGREE>();
-  static const DegreeImpl f32 = make_degree_impl<float, FUS_TU_DEGREE>();
-  return dtype == FUS_F64 ? &f64 : &f32;
+  static const DegreeImpl d = make_degree_impl<double, FUS_TU_DEGREE>();
+  return &d;
 }
+#else
+FUS_HIDDEN const DegreeImpl* FUS_CAT(FUS_CAT(fus_degree_impl_, FUS_TU_DEGREE), _f32)()
+{
+  static const DegreeImpl d = make_degree_impl<float, FUS_TU_DEGREE>();
+  return &d;
+}
+#endif
 #else  // main unit: everything from here to the end of the file
+#define FUS_DECL_DEGREE(k)                                                                         \
+  FUS_HIDDEN const DegreeImpl* FUS_CAT(FUS_CAT(fus_degree_impl_, k), _f64)();                      \
+  FUS_HIDDEN const DegreeImpl* FUS_CAT(FUS_CAT(fus_degree_impl_, k), _f32)();
+#define FUS_CASE_DEGREE(k)                                                                         \
+  case k:                                                                                          \
+    return dtype == FUS_F64 ? FUS_CAT(FUS_CAT(fus_degree_impl_, k), _f64)() : FUS_CAT(FUS_CAT(fus_degree_impl_, k), _f32)();
 #ifdef FUS_DEV_BUILD  // developer iteration build: ONE degree (never shipped; build.py --dev)
 #ifndef FUS_DEV_DEGREE
 #define FUS_DEV_DEGREE 4
 #endif
-FUS_HIDDEN const DegreeImpl* FUS_CAT(fus_degree_impl_, FUS_DEV_DEGREE)(int);
-static const DegreeImpl* degree_impl(int dtype, int P)
-{
-  return P == FUS_DEV_DEGREE ? FUS_CAT(fus_degree_impl_, FUS_DEV_DEGREE)(dtype) : nullptr;
-}
-#else
-FUS_HIDDEN const DegreeImpl* fus_degree_impl_2(int);
-FUS_HIDDEN const DegreeImpl* fus_degree_impl_3(int);
-FUS_HIDDEN const DegreeImpl* fus_degree_impl_4(int);
-FUS_HIDDEN const DegreeImpl* fus_degree_impl_5(int);
-FUS_HIDDEN const DegreeImpl* fus_degree_impl_6(int);
-FUS_HIDDEN const DegreeImpl* fus_degree_impl_7(int);
+FUS_DECL_DEGREE(FUS_DEV_DEGREE)
 static const DegreeImpl* degree_impl(int dtype, int P)
 {
   switch (P)
   {
-  case 2: return fus_degree_impl_2(dtype);
-  case 3: return fus_degree_impl_3(dtype);
-  case 4: return fus_degree_impl_4(dtype);
-  case 5: return fus_degree_impl_5(dtype);
-  case 6: return fus_degree_impl_6(dtype);
-  case 7: return fus_degree_impl_7(dtype);
+    FUS_CASE_DEGREE(FUS_DEV_DEGREE)
+  default: return nullptr;
+  }
+}
+#else
+FUS_DECL_DEGREE(2) FUS_DECL_DEGREE(3) FUS_DECL_DEGREE(4) FUS_DECL_DEGREE(5) FUS_DECL_DEGREE(6) FUS_DECL_DEGREE(7)
+static const DegreeImpl* degree_impl(int dtype, int P)
+{
+  switch (P)
+  {
+    FUS_CASE_DEGREE(2) FUS_CASE_DEGREE(3) FUS_CASE_DEGREE(4) FUS_CASE_DEGREE(5) FUS_CASE_DEGREE(6) FUS_CASE_DEGREE(7)
   default: return nullptr;
   }
 }
@@ -1693,6 +1772,20 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
       return fail(FUS_ERR_ARG, "forms must be 0 (C++ benchmark forms) or 1 (Python package forms)");
     c->forms = (int)value;
   }
+  else if (!strcmp(key, "lean_rk4"))
+    c->lean_rk4 = value != 0;
+  else if (!strcmp(key, "walk"))
+  {
+    if (value < -1 || value > 8)
+      return fail(FUS_ERR_ARG, "walk must be -1 (auto), 0 (one workgroup per block) or 1..8 workgroups per CU");
+    c->walk = (int)value;
+  }
+  else if (!strcmp(key, "mfma"))
+  {
+    if (value < -1 || value > 1)
+      return fail(FUS_ERR_ARG, "mfma must be -1 (auto), 0 or 1");
+    c->mfma = (int)value;
+  }
   else if (!strcmp(key, "fields"))
   {
     if (value != 1 && value != 2)
@@ -1993,6 +2086,7 @@ static void layout_info(const Layout& L, size_t ts, int64_t out[8])
 
 int fus_op_is_affine(fus_op* op) { return (op && op->affine) ? 1 : 0; }
 int fus_op_geometry_mode(fus_op* op) { return !op ? 0 : (op->affine ? 1 : (op->trilinear ? 2 : 0)); }
+int fus_op_uses_mfma(fus_op* op) { return (op && op->mfma) ? 1 : 0; }
 
 int fus_op_info(fus_op* op, int64_t out[8])
 {
@@ -2163,6 +2257,7 @@ int fus_model_create(fus_ctx* c, int kind, fus_op* op, const void* c0, const voi
   std::unique_ptr<fus_model> m(new fus_model());
   m->ctx = c, m->op = op, m->kind = kind, m->freq = freq, m->amp = amp, m->speed = speed;
   m->forms = c->forms;
+  m->lean_rk4 = c->lean_rk4;
   int r = d_model_setup(m.get(), c0, rho0, delta0, beta0, nfacets, facet_cells, facet_local, facet_tags);
   if (r == FUS_OK && !c->local_group)
   {
@@ -2499,12 +2594,11 @@ int fus_measure_bandwidth(fus_ctx* c, int64_t nbytes, int reps, double* gbps)
   HIPCHK(hipSetDevice(c->device));
   typedef double D2 __attribute__((ext_vector_type(2)));
   const int64_t nvec = nbytes / 16;
-  D2 *x = nullptr, *z = nullptr, *y = nullptr;
+  D2 *x = nullptr, *y = nullptr;
   HIPCHK(hipMalloc(&x, nvec * 16));
-  HIPCHK(hipMalloc(&z, nvec * 16));
   HIPCHK(hipMalloc(&y, nvec * 16));
   HIPCHK(hipMemsetAsync(x, 0, nvec * 16, c->stream));
-  HIPCHK(hipMemsetAsync(z, 0, nvec * 16, c->stream));
+  HIPCHK(hipMemsetAsync(y, 0, nvec * 16, c->stream));
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
@@ -2512,8 +2606,8 @@ int fus_measure_bandwidth(fus_ctx* c, int64_t nbytes, int reps, double* gbps)
   for (int r = 0; r < reps + 1; ++r)  // first launch is a warm-up
   {
     HIPCHK(hipEventRecord(e0, c->stream));
-    hipLaunchKernelGGL((k_triad<D2>), dim3(c->num_cus * 8), dim3(256), 0, c->stream, nvec,
-                       static_cast<const D2*>(x), static_cast<const D2*>(z), y, 0.5);
+    hipLaunchKernelGGL((k_stream_copy<D2>), dim3((unsigned)((nvec + 255) / 256)), dim3(256), 0, c->stream, nvec,
+                       static_cast<const D2*>(x), y);
     HIPCHK(hipEventRecord(e1, c->stream));
     HIPCHK(hipEventSynchronize(e1));
     float ms = 0;
@@ -2522,8 +2616,8 @@ int fus_measure_bandwidth(fus_ctx* c, int64_t nbytes, int reps, double* gbps)
       best = ms;
   }
   (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
-  (void)hipFree(x), (void)hipFree(z), (void)hipFree(y);
-  *gbps = 3.0 * (double)(nvec * 16) / (best * 1e-3) / 1e9;
+  (void)hipFree(x), (void)hipFree(y);
+  *gbps = 2.0 * (double)(nvec * 16) / (best * 1e-3) / 1e9;   // bytes read + bytes written
   return FUS_OK;
 }
 
@@ -2571,7 +2665,7 @@ int fus_profile_get(fus_ctx* c, const char* name, double* total_ms, int64_t* cou
 } // extern "C"
 #endif  // !FUS_TU_DEGREE
 
-#if defined(FUS_TRACE) && defined(FUS_TU_DEGREE)
+#if defined(FUS_TRACE) && defined(FUS_TU_DEGREE) && FUS_TU_DTYPE == 64
 // experiment builds: phase timestamps of the last k_block_op launch of this degree's unit
 extern "C" int fus_debug_trace(unsigned long long* out, long long nblocks)
 {

@@ -41,7 +41,8 @@ struct BlockArgs
   const int16_t* rounds;
   const uint16_t* ldm;
   int32_t nblocks;
-  int32_t blk_begin; // first block of this launch (grid = a contiguous range of blocks)
+  int32_t blk_begin; // first block of this launch (a contiguous range of blocks)
+  int32_t blk_count; // blocks of this launch; workgroup w walks blocks blk_begin + w, + gridDim.x, ...
   int32_t lds_nloc;  // LDS array length (>= max nloc, even)
   int32_t lds_nelem; // LDS per-element table length (>= max elements per block, multiple of 8)
   int32_t waves;
@@ -56,6 +57,10 @@ struct StageArgs
   const T* minv;
   T *vn, *un, *u0, *v0, *u_, *v_;
   T adt, bdt, gval;
+  // classical RK4 only (stage kinds 4-6, see stage_is_first): dt b_0, b_0 / a_1 and b_1 / a_2 of the
+  // Runge-Kutta tables, from which stages 1 and 2 rebuild the accumulators that stages 0 and 1 no longer
+  // write
+  T b0dt, r0, r1;
   const int32_t* blk_bnd_off;
   const int32_t* bnd_idx;
   const T* bnd_src;
@@ -77,6 +82,18 @@ enum
 {
   STAGE_NONE = -1  // plain operator action: b / partial slab are written, no update
 };
+
+// Fused stage-update variants (template parameter STAGE of the block and shared-dof kernels).
+//   0 first stage, 1 middle stage, 3 last stage of RK4: every stage keeps the accumulators u_, v_ in HBM
+//     the way Linear.hpp:282-294 does (used by the Runge-Kutta orders 1-3 and option "lean_rk4" = 0);
+//   4, 5, 6 = stages 0, 1, 2 of the classical RK4 with the redundant vector streams removed: the
+//     accumulators are affine in vectors the later stages read anyway,
+//         v_ after stage 0 = v0 + (b_0 / a_1) (vn_1 - v0)               [vn_1 = v0 + a_1 dt kv_0]
+//         u_ after stage 1 = u0 + b_0 dt v0 + (b_1 / a_2) (un_2 - u0)   [un_2 = u0 + a_2 dt vn_1]
+//     so stage 0 writes neither, stage 1 writes only v_ and stage 2 rebuilds u_ -- 240 instead of 296
+//     bytes of vector traffic per dof and step, the same arithmetic up to rounding (|error| ~ eps |u|,
+//     the size of the reference's own accumulation error).
+__host__ __device__ constexpr bool stage_is_first(int st) { return st == 0 || st == 4; }
 
 template <typename T, int N>
 struct DTab
@@ -647,6 +664,250 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// MFMA contraction path (degrees 6 and 7, per-cell geometry kernels; template parameter MF of k_block_op).
+// At N = 7, 8 one element fills a wave, and each of the index-1 / index-2 contractions of an element is an
+// (N x N) . (N x N^2) product -- the reference's contract<T, N, N, N, N, bool>
+// (cpp/fenicsx-sf/common/sum_factorisation.hpp:70-86).  It runs here on the matrix cores as 16 x 16 x 4
+// tiles (v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32; N = 7 is padded to 8 with zero table entries):
+//   A operand (lane l: row l & 15, k = l >> 4): the derivative table, D[q][k] (rows q >= N are zero),
+//                                               or its transpose for the second half of the operator;
+//   B operand (lane l: k = l >> 4, column l & 15): 16 columns = two tensor planes a = 2 t + (h >> 3) x 8
+//                                               values of the free index, read from the element's LDS tile;
+//   two k-steps (k = 4 s + g) per tile, four tiles (t) per direction: 8 MFMAs per direction and element,
+//   half of each tile's 16 result rows are padding (N <= 8 < 16).
+// The results go back through the tile to the lane-per-column layout the transform and the scatter use
+// (8 reads + 8 writes + 8 reads per lane and direction, like the re-mapped vector form); the index-0
+// contraction stays on the vector ALUs (registers only).  f64 MFMA issues at the vector FMA rate on gfx950,
+// so the gain, if any, is the vector ALU freed for the geometry recomputation running beside it.
+template <typename T>
+struct MfmaOp;
+template <>
+struct MfmaOp<double>
+{
+  typedef double V4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ V4 mma(double a, double b, V4 c)
+  {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of the f64 form: column = lane & 15, row = (lane >> 4) + 4 reg
+  static __device__ __forceinline__ int row(int g, int r) { return g + 4 * r; }
+};
+template <>
+struct MfmaOp<float>
+{
+  typedef float V4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ V4 mma(float a, float b, V4 c)
+  {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of the f32 form: column = lane & 15, row = 4 (lane >> 4) + reg
+  static __device__ __forceinline__ int row(int g, int r) { return 4 * g + r; }
+};
+
+// One directional contraction of the element in the tile: out[.., q, ..] = sum_k A[q][k] in[.., k, ..]
+// with the contracted index at stride SK and the free index at stride SF inside a plane of N^2 values.
+// Bm[t][s]: this lane's B operands (read from the tile by the caller before it is overwritten).
+template <typename T, int N, int SK, int SF>
+__device__ __forceinline__ void mfma_tile_contract(const T (&Am)[2], const T (&Bm)[4][2], T* __restrict__ sA, int g,
+                                                   int ha, int hc)
+{
+  constexpr int N2 = N * N;
+  typedef typename MfmaOp<T>::V4 V4;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+  {
+    V4 acc = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+      acc = MfmaOp<T>::mma(Am[s], Bm[t][s], acc);
+    const int a = 2 * t + ha;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+    {
+      const int q = MfmaOp<T>::row(g, r);
+      if (q < N && a < N && hc < N)
+        sA[a * N2 + q * SK + hc * SF] = acc[r];
+    }
+  }
+}
+
+template <typename T, int N, int SK, int SF>
+__device__ __forceinline__ void mfma_tile_operands(T (&Bm)[4][2], const T* __restrict__ sA, int g, int ha, int hc)
+{
+  constexpr int N2 = N * N;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+    {
+      const int a = 2 * t + ha, k = 4 * s + g;
+      // padding (N = 7) reads a valid, finite tile entry; its table entry is zero
+      Bm[t][s] = sA[(a < N && k < N && hc < N) ? a * N2 + k * SK + hc * SF : 0];
+    }
+}
+
+template <typename T, int N, int ATOMIC, int NF, int GEOM>
+__device__ __forceinline__ void elem_compute_mfma(const ElemIn<T, N, OP_STIFFNESS, GEOM>& in, const DTab<T, N>& Dk,
+                                                  const T* __restrict__ x_l, T* __restrict__ y_l,
+                                                  T* __restrict__ sA, const uint16_t* __restrict__ ldm_l,
+                                                  const T* __restrict__ cf_l, const T* __restrict__ x2_l,
+                                                  const T* __restrict__ cf2_l, const T* __restrict__ gc_l,
+                                                  const T (&w3)[N], const T* __restrict__ D_l, T wbc, T pb, T pc,
+                                                  int p, int lane)
+{
+  static_assert(N == 7 || N == 8, "one element per wave, table padded to 8");
+  static_assert(GEOM == GEOM_AFFINE || GEOM == GEOM_TRILINEAR, "per-cell geometry kernels");
+  constexpr int N2 = N * N, Nd = N * N * N;
+  // one element per wave (EPW = 1): lane 0 always holds it; lanes >= N^2 (N = 7) carry no tensor column
+  // but take part in the matrix instructions
+  const int er = __builtin_amdgcn_readfirstlane(in.er);
+  if (er < 0)
+    return;
+  const bool on = in.er >= 0;
+  const int g = lane >> 4, h = lane & 15, ha = h >> 3, hc = h & 7;
+  T Af[2], At[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+  {
+    const int k = 4 * s + g;
+    const bool ok = h < N && k < N;
+    Af[s] = ok ? D_l[h * N + k] : T(0);  // A[row q = h][k]     = D[q][k]
+    At[s] = ok ? D_l[k * N + h] : T(0);  // A[row j = h][k = q] = D[q][j]
+  }
+  TriLane<T> tri;
+  if (GEOM == GEOM_TRILINEAR)
+    tri.init(gc_l + er * 21, pb, pc);
+  int li[N];
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    li[a] = on ? (int)ldm_l[er * Nd + a * N2 + p] : 0;
+  const T cf = (NF == 2) ? T(1) : cf_l[er];
+  T X[N], F0[N], F1[N], F2[N], Y[N];
+  if (NF == 2)
+  {
+    const T c1 = cf_l[er], c2 = cf2_l[er];
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      X[a] = c1 * x_l[li[a]] + c2 * x2_l[li[a]];
+  }
+  else
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      X[a] = x_l[li[a]];
+  }
+  // derivative along tensor index 0: registers only (spectral_op.hpp:194-196)
+#pragma unroll
+  for (int q = 0; q < N; ++q)
+  {
+    T acc = T(0);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      acc += Dk.d[q * N + i] * X[i];
+    F0[q] = acc;
+  }
+  if (on)
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      sA[a * N2 + p] = X[a];
+  }
+  FUS_WAVE_SYNC();
+  // derivatives along tensor indices 1 and 2 (spectral_op.hpp:199-210) on the matrix cores
+  T B1[4][2], B2[4][2];
+  mfma_tile_operands<T, N, N, 1>(B1, sA, g, ha, hc);   // contracted index 1 (stride N), free index 2
+  mfma_tile_operands<T, N, 1, N>(B2, sA, g, ha, hc);   // contracted index 2 (stride 1), free index 1
+  FUS_WAVE_SYNC();
+  mfma_tile_contract<T, N, N, 1>(Af, B1, sA, g, ha, hc);
+  FUS_WAVE_SYNC();
+  if (on)
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      F1[a] = sA[a * N2 + p];
+  }
+  FUS_WAVE_SYNC();
+  mfma_tile_contract<T, N, 1, N>(Af, B2, sA, g, ha, hc);
+  FUS_WAVE_SYNC();
+  if (on)
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      F2[a] = sA[a * N2 + p];
+  }
+  // stiffness::transform (spectral_op.hpp:113-130)
+  if (on)
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      if (GEOM == GEOM_TRILINEAR)
+        tri.transform(Dk.x[a], Dk.w[a] * wbc * cf, F0[a], F1[a], F2[a]);
+      else
+      {
+        T G6[6];
+#pragma unroll
+        for (int gi = 0; gi < 6; ++gi)
+          G6[gi] = gc_l[er * 7 + gi] * w3[a];
+        const T w0 = F0[a], w1 = F1[a], w2 = F2[a];
+        F0[a] = cf * (G6[0] * w0 + G6[1] * w1 + G6[2] * w2);
+        F1[a] = cf * (G6[1] * w0 + G6[3] * w1 + G6[4] * w2);
+        F2[a] = cf * (G6[2] * w0 + G6[4] * w1 + G6[5] * w2);
+      }
+    }
+  }
+  // transposed contractions (spectral_op.hpp:222-238)
+  FUS_WAVE_SYNC();
+  if (on)
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      sA[a * N2 + p] = F1[a];
+  }
+  FUS_WAVE_SYNC();
+  mfma_tile_operands<T, N, N, 1>(B1, sA, g, ha, hc);
+  FUS_WAVE_SYNC();
+  mfma_tile_contract<T, N, N, 1>(At, B1, sA, g, ha, hc);
+  FUS_WAVE_SYNC();
+  if (on)
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      T acc = sA[a * N2 + p];
+#pragma unroll
+      for (int q = 0; q < N; ++q)
+        acc += Dk.d[q * N + a] * F0[q];
+      Y[a] = acc;
+    }
+  }
+  FUS_WAVE_SYNC();
+  if (on)
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      sA[a * N2 + p] = F2[a];
+  }
+  FUS_WAVE_SYNC();
+  mfma_tile_operands<T, N, 1, N>(B2, sA, g, ha, hc);
+  FUS_WAVE_SYNC();
+  mfma_tile_contract<T, N, 1, N>(At, B2, sA, g, ha, hc);
+  FUS_WAVE_SYNC();
+  if (on)
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      Y[a] += sA[a * N2 + p];
+      if (ATOMIC)
+        __hip_atomic_fetch_add(&y_l[li[a]], Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else
+        y_l[li[a]] += Y[a];
+    }
+  }
+}
+
 // The stiffness pass of elem_compute in two halves, for the single-register-set schedule of the
 // degrees 5 and 6 (k_block_op, PF1): elem_stiff_fwd ends with the transform -- the last reader of in.g --,
 // the kernel then requests the next element's geometry into the same registers, and elem_stiff_bwd
@@ -802,6 +1063,122 @@ __device__ __forceinline__ void elem_stiff_bwd(const DTab<T, N>& Dk, const T (&D
 #endif
 #endif
 
+// Fused RK4 stage update of ONE dof s whose right-hand side sum `acc` (= b) is complete.
+// kv = b * minv  (Linear.hpp:212-221), ku = vn (f0, :171-174).
+//   STAGE 0 : vn == v0, un == u0, u_ == u0, v_ == v0 (aliases are not read twice)
+//             u_ = u0 + bdt*v0 ; v_ = v0 + bdt*kv ; un' = u0 + adt*v0 ; vn' = v0 + adt*kv
+//   STAGE 1,2: u_ += bdt*vn ; v_ += bdt*kv ; un' = u0 + adt*vn ; vn' = v0 + adt*kv
+//   STAGE 3 : u0 = u_ + bdt*vn ; v0 = v_ + bdt*kv        (next step's state, no copies)
+// adt = dt*a_{i+1}, bdt = dt*b_i (Linear.hpp:282-294).
+//
+// Model vectors are read / written once per stage: non-temporal, so that the partial slab (written
+// just before by k_block_op) stays cache resident.
+template <typename T>
+struct LeanRK
+{
+  T b0dt, r0, r1;   // see StageArgs
+};
+
+template <typename T, int STAGE>
+__device__ __forceinline__ T stage_update_dof(int64_t s, T acc, const T* __restrict__ minv,
+                                                 T* __restrict__ vn, T* __restrict__ un,
+                                                 T* __restrict__ u0, T* __restrict__ v0,
+                                                 T* __restrict__ u_, T* __restrict__ v_, T adt, T bdt,
+                                                 const T* __restrict__ m0, const T* __restrict__ mn1,
+                                                 const LeanRK<T> R)
+{
+#define FUS_LD(p) __builtin_nontemporal_load(&(p)[s])
+#define FUS_ST(p, val) __builtin_nontemporal_store((val), &(p)[s])
+  T kv;
+  if (mn1)  // Westervelt (see StageArgs): stage inputs u_n, v_n are u0, v0 at the first stage
+  {
+    const T us = stage_is_first(STAGE) ? u0[s] : un[s], vs = stage_is_first(STAGE) ? v0[s] : vn[s];
+    kv = (acc - mn1[s] * vs * vs) / (m0[s] + mn1[s] * us);
+  }
+  else
+    kv = acc * FUS_LD(minv);
+  T vnext;  // the velocity the NEXT stage starts from: vn' (stages 0-2) or the new v0 (stage 3)
+  if (STAGE == 0)
+  {
+    const T u = FUS_LD(u0), v = FUS_LD(v0);
+    FUS_ST(u_, v * bdt + u);
+    FUS_ST(v_, kv * bdt + v);
+    FUS_ST(un, v * adt + u);
+    vnext = kv * adt + v;
+    FUS_ST(vn, vnext);
+  }
+  else if (STAGE == 4)
+  {
+    const T u = FUS_LD(u0), v = FUS_LD(v0);
+    FUS_ST(un, v * adt + u);
+    vnext = kv * adt + v;
+    FUS_ST(vn, vnext);
+  }
+  else if (STAGE == 3)
+  {
+    FUS_ST(u0, FUS_LD(vn) * bdt + FUS_LD(u_));
+    vnext = kv * bdt + FUS_LD(v_);
+    FUS_ST(v0, vnext);
+  }
+  else if (STAGE == 5)
+  {
+    const T w = FUS_LD(vn), u = FUS_LD(u0), v = FUS_LD(v0);
+    FUS_ST(v_, kv * bdt + ((w - v) * R.r0 + v));
+    FUS_ST(un, w * adt + u);
+    vnext = kv * adt + v;
+    FUS_ST(vn, vnext);
+  }
+  else if (STAGE == 6)
+  {
+    const T w = FUS_LD(vn), u = FUS_LD(u0), v = FUS_LD(v0), xs = FUS_LD(un);
+    FUS_ST(u_, w * bdt + ((xs - u) * R.r1 + (v * R.b0dt + u)));
+    FUS_ST(v_, kv * bdt + FUS_LD(v_));
+    FUS_ST(un, w * adt + u);
+    vnext = kv * adt + v;
+    FUS_ST(vn, vnext);
+  }
+  else
+  {
+    const T w = FUS_LD(vn);
+    FUS_ST(u_, w * bdt + FUS_LD(u_));
+    FUS_ST(v_, kv * bdt + FUS_LD(v_));
+    FUS_ST(un, w * adt + FUS_LD(u0));
+    vnext = kv * adt + FUS_LD(v0);
+    FUS_ST(vn, vnext);
+  }
+#undef FUS_LD
+#undef FUS_ST
+  return vnext;
+}
+
+// The block kernel's only argument (read in the kernel through the kernarg segment pointer, see FUS_KARGS).
+template <typename T, int N>
+struct KArgs
+{
+  BlockArgs A;
+  DTab<T, N> Dk;
+  const T* Dg;
+  const T* geo;
+  const T* coef;
+  const T* x;
+  T* bvec;
+  T* partial;
+  StageArgs<T> S;
+};
+
+template <typename T, int N>
+__device__ __forceinline__ void load_stage_args(const KArgs<T, N> __attribute__((address_space(4))) * q, StageArgs<T>& S)
+{
+  S.minv = q->S.minv;
+  S.vn = q->S.vn, S.un = q->S.un, S.u0 = q->S.u0, S.v0 = q->S.v0, S.u_ = q->S.u_, S.v_ = q->S.v_;
+  S.adt = q->S.adt, S.bdt = q->S.bdt, S.gval = q->S.gval;
+  S.b0dt = q->S.b0dt, S.r0 = q->S.r0, S.r1 = q->S.r1;
+  S.blk_bnd_off = q->S.blk_bnd_off, S.bnd_idx = q->S.bnd_idx;
+  S.bnd_src = q->S.bnd_src, S.bnd_abs = q->S.bnd_abs;
+  S.x2 = q->S.x2, S.coef2 = q->S.coef2, S.bnd_src2 = q->S.bnd_src2, S.dgval = q->S.dgval;
+  S.m0 = q->S.m0, S.mn1 = q->S.mn1;
+}
+
 // Block operator:  bvec[interior dofs of block] = (A x)[...],  partial[(block, shared slot)] =
 // this block's contribution to a shared dof.  x, bvec in internal numbering.
 // geo = G (6*Nd per element, per-lane vector layout) for OP_STIFFNESS, detJw (Nd per element,
@@ -818,177 +1195,239 @@ __device__ __forceinline__ void elem_stiff_bwd(const DTab<T, N>& Dk, const T (&D
 // no geometry registers -- are compiled for FUS_TRI_WAVES(P) waves per SIMD with the lane's
 // derivative-table rows read from LDS where used.
 // TD = 2: the same block machinery for quadrilateral elements (Nd = N^2, GEOM_STREAM only).
-template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3>
+template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3, int MF = 0>
 __global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P <= 4 && GEOM == GEOM_AFFINE)
                                                             ? 4
                                                             : ((GEOM == GEOM_TRILINEAR || (GEOM == GEOM_AFFINE && P <= 6)) ? FUS_TRI_WAVES(P) : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1)))
-k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
-           const T* __restrict__ geo, const T* __restrict__ coef, const T* __restrict__ x,
-           T* __restrict__ bvec, T* __restrict__ partial, const StageArgs<T> S)
+k_block_op(const KArgs<T, P + 1> kernel_args)
 {
   static_assert(TD == 3 || GEOM == GEOM_STREAM, "quadrilaterals use the streamed geometry");
   constexpr int N = P + 1, N2 = N * N, Nd = (TD == 3) ? N * N * N : N * N;
   constexpr int EPW = (64 / N2) > 0 ? (64 / N2) : 1;
 
-  extern __shared__ __align__(16) unsigned char smem_raw[];
-  T* x_l = reinterpret_cast<T*>(smem_raw);
-  T* y_l = x_l + A.lds_nloc;
-  T* x2_l = y_l + A.lds_nloc;                               // second input (NF == 2 only)
-  T* scratch = x2_l + (NF == 2 ? A.lds_nloc : 0);
-  T* D_l = scratch + (size_t)A.waves * EPW * (Nd + N);     // derivative table (tiles: Nd + N each, see elem_compute REMAP)
-  T* cf_l = D_l + N2;                                       // per-element coefficient(s)
-  T* cf2_l = cf_l + A.lds_nelem;
+  (void)kernel_args;
+  // Kernel arguments are read from the kernarg segment where they are used, through a pointer that is
+  // made opaque again at the start of every phase (FUS_KARGS): a workgroup that walks several blocks
+  // would otherwise keep all ~150 scalar registers' worth of arguments live around the block loop and
+  // spill them.
+  typedef const KArgs<T, N> __attribute__((address_space(4))) * KP;
+#define FUS_KARGS(q)                                                                               \
+  KP q = (KP)__builtin_amdgcn_kernarg_segment_ptr();                             \
+  asm volatile("" : "+s"(q))
   constexpr int GCS = geom_cell_stride(GEOM);               // per-cell geometry numbers (7 / 21 / 0)
-  T* gc_l = cf2_l + (NF == 2 ? A.lds_nelem : 0);            // affine: 6 G + 1 detJ; trilinear: 21 map coefficients
-  T* w_l = gc_l + GCS * A.lds_nelem;                        // 1-D weights (8 slots), 1-D points (8 slots)
-  T* pt_l = w_l + 8;
-  uint16_t* ldm_l = reinterpret_cast<uint16_t*>(w_l + (GCS ? 16 : 0));  // 16-B aligned
-  int16_t* rt_l = reinterpret_cast<int16_t*>(ldm_l + (size_t)A.lds_nelem * Nd);
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  // LDS carve, re-derived from the kernel arguments in every phase (nothing of it is carried around the
+  // block loop in scalar registers)
+#define FUS_PHASE_LDS(q)                                                                           \
+  const int lds_nloc = q->A.lds_nloc, lds_nelem = q->A.lds_nelem, nwaves = q->A.waves;             \
+  const int slots = nwaves * EPW;                                                                  \
+  T* x_l = reinterpret_cast<T*>(smem_raw);                                                         \
+  T* y_l = x_l + lds_nloc;                                                                         \
+  T* x2_l = y_l + lds_nloc; /* second input (NF == 2 only) */                                      \
+  T* scratch = x2_l + (NF == 2 ? lds_nloc : 0);                                                    \
+  T* D_l = scratch + (size_t)nwaves * EPW * (Nd + N); /* derivative table (tiles: Nd + N each) */  \
+  T* cf_l = D_l + N2; /* per-element coefficient(s) */                                             \
+  T* cf2_l = cf_l + lds_nelem;                                                                     \
+  T* gc_l = cf2_l + (NF == 2 ? lds_nelem : 0); /* affine: 6 G + 1 detJ; trilinear: 21 map coefficients */ \
+  T* w_l = gc_l + GCS * lds_nelem; /* 1-D weights (8 slots), 1-D points (8 slots) */               \
+  T* pt_l = w_l + 8;                                                                               \
+  uint16_t* ldm_l = reinterpret_cast<uint16_t*>(w_l + (GCS ? 16 : 0)); /* 16-B aligned */          \
+  int16_t* rt_l = reinterpret_cast<int16_t*>(ldm_l + (size_t)lds_nelem * Nd);                      \
+  (void)y_l, (void)x2_l, (void)scratch, (void)D_l, (void)cf_l, (void)cf2_l, (void)gc_l, (void)w_l, (void)pt_l,      \
+      (void)ldm_l, (void)rt_l, (void)slots
 
-  const int blk = blockIdx.x + A.blk_begin;
-  const int tid = threadIdx.x, nthr = blockDim.x;
-  const ShapeDev sh = A.shapes[A.blk_shape[blk]];
-  const int elem_off = A.blk_elem_off[blk];
-  const int int_off = A.blk_int_off[blk];
-  const int64_t sh_off = A.blk_sh_off[blk];
+  const int tid0 = threadIdx.x, nthr = blockDim.x;
+  // the thread index, opaque per phase like the lane coordinates (FUS_TID): address arithmetic of one phase
+  // must not be hoisted out of the block loop and stay live through the others
+#define FUS_TID()                                                                                  \
+  int tid = tid0;                                                                                  \
+  asm volatile("" : "+v"(tid))
+  // lane coordinates: recomputed per block from a value the compiler cannot trace (FUS_LANE_COORDS), so that
+  // the address arithmetic of the element trips is not hoisted out of the block loop of a walking
+  // workgroup and kept live (and spilled) across its prologue / epilogue phases
+#define FUS_LANE_COORDS(q)                                                                         \
+  FUS_TID();                                                                                       \
+  const int lane = tid & 63, wave = tid >> 6;                                                    \
+  const int s = lane / N2, p = lane - s * N2;                                                      \
+  const int b = p / N, c = p - b * N;                                                              \
+  const bool active = s < EPW;                                                                     \
+  const int myslot = wave * EPW + (active ? s : 0);                                                \
+  /* exchange tiles follow x_l, y_l (, x2_l); one per element slot */                              \
+  T* sA = reinterpret_cast<T*>(smem_raw) + (size_t)(NF == 2 ? 3 : 2) * q->A.lds_nloc                \
+          + (size_t)(wave * EPW + (active ? s : 0)) * (Nd + N);                                    \
+  T* sB = sA
 
-  const int lane = tid & 63, wave = tid >> 6;
-  const int s = lane / N2, p = lane - s * N2;
-  const int b = p / N, c = p - b * N;
-  const bool active = s < EPW;
-  const int slots = A.waves * EPW;
-  const int myslot = wave * EPW + (active ? s : 0);
-  // element of this lane group in trip r: conflict-free round table (deterministic mode) or simply
-  // the next `slots` elements (atomic mode: no ordering constraint between waves)
-  const int ntrips = ATOMIC ? (sh.nelem + slots - 1) / slots : sh.nrounds;
-  auto elem_of = [&](int r) -> int
+  // A workgroup walks the blocks blk, blk + gridDim.x, ... of the launch's range (a launch with one
+  // workgroup per block walks one).  While it writes out block k (the epilogue's loads and stores) the
+  // global loads of block k + 1's prologue are already in flight, so the two memory-latency phases of
+  // consecutive blocks overlap instead of following each other.
+  struct Meta
   {
-    if (!active || r >= ntrips)
-      return -1;
-    if (ATOMIC)
-      return (r * slots + myslot < sh.nelem) ? r * slots + myslot : -1;
-    return (int)rt_l[r * slots + myslot];
+    ShapeDev sh;
+    int elem_off, int_off;
+    int64_t sh_off;
   };
-
-  FUS_STAMP(blk, 0);
-  // first trip's geometry is requested before the block's dof values are staged
-  ElemIn<T, N, OP, GEOM, TD> inA, inB;
+  auto meta_of = [&](KP q, int bk) -> Meta
   {
-    int e0 = -1;
-    if (active && ntrips > 0)
-      e0 = ATOMIC ? (myslot < sh.nelem ? myslot : -1) : (int)A.rounds[sh.rounds_off + myslot];
-    elem_fetch<T, N, OP, GEOM, TD>(inA, e0, geo, elem_off, p);
-  }
-
+    Meta M;
+    M.sh = q->A.shapes[q->A.blk_shape[bk]];
+    M.elem_off = q->A.blk_elem_off[bk];
+    M.int_off = q->A.blk_int_off[bk];
+    M.sh_off = q->A.blk_sh_off[bk];
+    return M;
+  };
+  typedef T V2 __attribute__((ext_vector_type(2)));
+  typedef uint32_t U4 __attribute__((ext_vector_type(4)));
+  // per thread: interior 16-B vectors, shared dofs, dofmap 16-B vectors of the first batch (what a block
+  // of the default size needs; larger blocks finish in the plain loops of p_commit).  Kept small: these
+  // registers are live across the epilogue of the previous block when a workgroup walks several blocks.
+  constexpr int UI = (P <= 3) ? 3 : ((P == 4) ? 2 : 4), US = (P <= 3) ? 4 : ((P == 4) ? 3 : 5),
+                UL = (P <= 3) ? 2 : ((P == 4) ? 1 : 4);
   // ---- prologue: stage the block's dof values, local dofmaps and coefficients in LDS, clear the
-  // accumulator.  Measured (phase timestamps, tools/gpu_trace.py) the prologue was the longest phase
-  // of a block when each of its copy loops waited for its own memory round trip, so every load that
-  // does not depend on another is issued first (one round trip), the gather of the shared dofs
-  // (it needs their indices) second, and only then the LDS stores.  Blocks larger than the first
-  // batches finish in plain loops. ----
+  // accumulator.  Every load that does not depend on another is issued first (one round trip), the
+  // gather of the shared dofs (it needs their indices) second (p_load); the LDS stores follow in p_commit.
+  // Blocks larger than the first batches finish in plain loops there. ----
+  struct PLoad
   {
-    typedef T V2 __attribute__((ext_vector_type(2)));
-    typedef uint32_t U4 __attribute__((ext_vector_type(4)));
-    constexpr int UI = 4, US = 5, UL = 4;  // per thread: interior 16-B vectors, shared dofs, dofmap 16-B vectors
-    const V2* xg = reinterpret_cast<const V2*>(x + int_off);  // int_off is a multiple of 16
-    const V2* xg2 = reinterpret_cast<const V2*>((NF == 2 ? S.x2 : x) + int_off);
-    const int nvec = sh.nint >> 1;
-    const int nsh = sh.nloc - sh.nint;
-    const int32_t* gix = A.sh_gidx + sh_off;
-    const int n16 = (sh.nelem * Nd * 2 + 15) >> 4;  // ldm_off is a multiple of 8 entries
-    const U4* lsrc = reinterpret_cast<const U4*>(A.ldm + sh.ldm_off);
-    const int ngc = sh.nelem * GCS;
-
-    // round trip 1
     V2 xi[UI], xi2[UI];
-    int gi[US];
+    T xs[US], xs2[US];
     U4 lq[UL];
-#pragma unroll
-    for (int u = 0; u < UI; ++u)
-      if (tid + u * nthr < nvec)
-      {
-        xi[u] = xg[tid + u * nthr];
-        if (NF == 2)
-          xi2[u] = xg2[tid + u * nthr];
-      }
+    T cfv, cf2v, gcv, gcv2, dgv, xtail, xtail2;
+  };
+  // indices of the block's shared dofs (the gather of their values depends on them: requested a phase early)
+  auto p_idx = [&](KP q, const Meta& M, bool enable, int (&gi)[US]) __attribute__((always_inline))
+  {
+    FUS_TID();
+    const int nsh = M.sh.nloc - M.sh.nint;
+    const int32_t* gix = q->A.sh_gidx + M.sh_off;
 #pragma unroll
     for (int u = 0; u < US; ++u)
-      gi[u] = (tid + u * nthr < nsh) ? gix[tid + u * nthr] : 0;
+      gi[u] = (enable && tid + u * nthr < nsh) ? gix[tid + u * nthr] : -1;
+  };
+  auto p_load = [&](KP q, const Meta& M, PLoad& L, bool with_tables, bool enable, const int (&gi)[US])
+      __attribute__((always_inline))
+  {
+    FUS_TID();
+    const ShapeDev& sh = M.sh;
+    const T* __restrict__ x = q->x;
+    const T* __restrict__ x2 = (NF == 2) ? q->S.x2 : x;
+    const T* __restrict__ coef = q->coef;
+    const T* __restrict__ coef2 = (NF == 2) ? q->S.coef2 : coef;
+    const T* __restrict__ geo = q->geo;
+    const T* __restrict__ Dg = q->Dg;
+    const V2* xg = reinterpret_cast<const V2*>(x + M.int_off);  // int_off is a multiple of 16
+    const V2* xg2 = reinterpret_cast<const V2*>(x2 + M.int_off);
+    const int nvec = sh.nint >> 1;
+    const int nsh = sh.nloc - sh.nint;
+    const int32_t* gix = q->A.sh_gidx + M.sh_off;
+    const int n16 = (sh.nelem * Nd * 2 + 15) >> 4;  // ldm_off is a multiple of 8 entries
+    const U4* lsrc = reinterpret_cast<const U4*>(q->A.ldm + sh.ldm_off);
+    const int ngc = sh.nelem * GCS;
+    // round trip 1
+    // (every field is assigned unconditionally: a register that is only written under a condition
+    // would have to stay live across the element trips of a walking workgroup)
+#pragma unroll
+    for (int u = 0; u < UI; ++u)
+    {
+      const bool ok = enable && tid + u * nthr < nvec;
+      L.xi[u] = ok ? xg[tid + u * nthr] : V2(T(0));
+      L.xi2[u] = (NF == 2 && ok) ? xg2[tid + u * nthr] : V2(T(0));
+    }
 #pragma unroll
     for (int u = 0; u < UL; ++u)
-      if (tid + u * nthr < n16)
-        lq[u] = lsrc[tid + u * nthr];
-    const T cfv = (tid < sh.nelem) ? coef[elem_off + tid] : T(0);
-    const T cf2v = (NF == 2 && tid < sh.nelem) ? S.coef2[elem_off + tid] : T(0);
-    const T gcv = (tid < ngc) ? geo[(int64_t)elem_off * GCS + tid] : T(0);
-    const T gcv2 = (GCS > 7 && tid + nthr < ngc) ? geo[(int64_t)elem_off * GCS + tid + nthr] : T(0);
-    const T dgv = (tid < N2 + 2 * N) ? Dg[tid] : T(0);  // derivative table, 1-D weights, 1-D points
-    const T xtail = (tid == 0 && (sh.nint & 1)) ? x[int_off + sh.nint - 1] : T(0);
-    const T xtail2 = (NF == 2 && tid == 0 && (sh.nint & 1)) ? S.x2[int_off + sh.nint - 1] : T(0);
-    // round trip 2: the shared dofs' values
-    T xs[US], xs2[US];
+      L.lq[u] = (enable && tid + u * nthr < n16) ? lsrc[tid + u * nthr] : U4(0u);
+    L.cfv = (enable && tid < sh.nelem) ? coef[M.elem_off + tid] : T(0);
+    L.cf2v = (NF == 2 && enable && tid < sh.nelem) ? coef2[M.elem_off + tid] : T(0);
+    L.gcv = (enable && tid < ngc) ? geo[(int64_t)M.elem_off * GCS + tid] : T(0);
+    L.gcv2 = (GCS > 7 && enable && tid + nthr < ngc) ? geo[(int64_t)M.elem_off * GCS + tid + nthr] : T(0);
+    L.dgv = (with_tables && enable && tid < N2 + 2 * N) ? Dg[tid] : T(0);  // derivative table, 1-D weights, 1-D points
+    L.xtail = (enable && tid == 0 && (sh.nint & 1)) ? x[M.int_off + sh.nint - 1] : T(0);
+    L.xtail2 = (NF == 2 && enable && tid == 0 && (sh.nint & 1)) ? x2[M.int_off + sh.nint - 1] : T(0);
+    // the shared dofs' values (their indices came with p_idx)
 #pragma unroll
     for (int u = 0; u < US; ++u)
     {
-      xs[u] = x[gi[u]];
-      if (NF == 2)
-        xs2[u] = S.x2[gi[u]];
+      L.xs[u] = gi[u] >= 0 ? x[gi[u]] : T(0);
+      L.xs2[u] = (NF == 2 && gi[u] >= 0) ? x2[gi[u]] : T(0);
     }
+  };
+  auto p_commit = [&](KP q, const Meta& M, const PLoad& L, bool with_tables) __attribute__((always_inline))
+  {
+    FUS_PHASE_LDS(q);
+    FUS_TID();
+    const ShapeDev& sh = M.sh;
+    const T* __restrict__ x = q->x;
+    const T* __restrict__ x2 = (NF == 2) ? q->S.x2 : x;
+    const T* __restrict__ coef = q->coef;
+    const T* __restrict__ coef2 = (NF == 2) ? q->S.coef2 : coef;
+    const T* __restrict__ geo = q->geo;
+    const T* __restrict__ Dg = q->Dg;
+    const V2* xg = reinterpret_cast<const V2*>(x + M.int_off);
+    const V2* xg2 = reinterpret_cast<const V2*>(x2 + M.int_off);
+    const int nvec = sh.nint >> 1;
+    const int nsh = sh.nloc - sh.nint;
+    const int32_t* gix = q->A.sh_gidx + M.sh_off;
+    const int n16 = (sh.nelem * Nd * 2 + 15) >> 4;
+    const U4* lsrc = reinterpret_cast<const U4*>(q->A.ldm + sh.ldm_off);
+    const int ngc = sh.nelem * GCS;
     // LDS stores
 #pragma unroll
     for (int u = 0; u < UI; ++u)
       if (tid + u * nthr < nvec)
       {
-        reinterpret_cast<V2*>(x_l)[tid + u * nthr] = xi[u];
+        reinterpret_cast<V2*>(x_l)[tid + u * nthr] = L.xi[u];
         if (NF == 2)
-          reinterpret_cast<V2*>(x2_l)[tid + u * nthr] = xi2[u];
+          reinterpret_cast<V2*>(x2_l)[tid + u * nthr] = L.xi2[u];
         reinterpret_cast<V2*>(y_l)[tid + u * nthr] = V2(T(0));
       }
 #pragma unroll
     for (int u = 0; u < UL; ++u)
       if (tid + u * nthr < n16)
-        reinterpret_cast<U4*>(ldm_l)[tid + u * nthr] = lq[u];
+        reinterpret_cast<U4*>(ldm_l)[tid + u * nthr] = L.lq[u];
     if (tid < sh.nelem)
     {
-      cf_l[tid] = cfv;
+      cf_l[tid] = L.cfv;
       if (NF == 2)
-        cf2_l[tid] = cf2v;
+        cf2_l[tid] = L.cf2v;
     }
     if (tid < ngc)
-      gc_l[tid] = gcv;
+      gc_l[tid] = L.gcv;
     if (GCS > 7 && tid + nthr < ngc)
-      gc_l[tid + nthr] = gcv2;
-    if (tid < N2)
-      D_l[tid] = dgv;
-    if (GCS && tid >= N2 && tid < N2 + N)
-      w_l[tid - N2] = dgv;
-    if (GCS && tid >= N2 + N && tid < N2 + 2 * N)
-      pt_l[tid - N2 - N] = dgv;
-    // (a one-wave workgroup at the higher degrees has fewer threads than table entries)
-    for (int k = tid + nthr; k < N2 + 2 * N; k += nthr)
+      gc_l[tid + nthr] = L.gcv2;
+    if (with_tables)
     {
-      const T v = Dg[k];
-      if (k < N2)
-        D_l[k] = v;
-      else if (GCS && k < N2 + N)
-        w_l[k - N2] = v;
-      else if (GCS)
-        pt_l[k - N2 - N] = v;
+      if (tid < N2)
+        D_l[tid] = L.dgv;
+      if (GCS && tid >= N2 && tid < N2 + N)
+        w_l[tid - N2] = L.dgv;
+      if (GCS && tid >= N2 + N && tid < N2 + 2 * N)
+        pt_l[tid - N2 - N] = L.dgv;
+      // (a one-wave workgroup at the higher degrees has fewer threads than table entries)
+      for (int k = tid + nthr; k < N2 + 2 * N; k += nthr)
+      {
+        const T v = Dg[k];
+        if (k < N2)
+          D_l[k] = v;
+        else if (GCS && k < N2 + N)
+          w_l[k - N2] = v;
+        else if (GCS)
+          pt_l[k - N2 - N] = v;
+      }
     }
     if (tid == 0 && (sh.nint & 1))
     {
-      x_l[sh.nint - 1] = xtail;
+      x_l[sh.nint - 1] = L.xtail;
       if (NF == 2)
-        x2_l[sh.nint - 1] = xtail2;
+        x2_l[sh.nint - 1] = L.xtail2;
       y_l[sh.nint - 1] = T(0);
     }
 #pragma unroll
     for (int u = 0; u < US; ++u)
       if (tid + u * nthr < nsh)
       {
-        x_l[sh.nint + tid + u * nthr] = xs[u];
+        x_l[sh.nint + tid + u * nthr] = L.xs[u];
         if (NF == 2)
-          x2_l[sh.nint + tid + u * nthr] = xs2[u];
+          x2_l[sh.nint + tid + u * nthr] = L.xs2[u];
         y_l[sh.nint + tid + u * nthr] = T(0);
       }
     // leftovers of large blocks (higher degrees), again with the loads of a batch ahead of its stores
@@ -1026,7 +1465,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
       {
         v[u] = x[g[u]];
         if (NF == 2)
-          v2[u] = S.x2[g[u]];
+          v2[u] = x2[g[u]];
       }
 #pragma unroll
       for (int u = 0; u < UB; ++u)
@@ -1052,48 +1491,123 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     }
     for (int k = tid + nthr; k < sh.nelem; k += nthr)
     {
-      cf_l[k] = coef[elem_off + k];
+      cf_l[k] = coef[M.elem_off + k];
       if (NF == 2)
-        cf2_l[k] = S.coef2[elem_off + k];
+        cf2_l[k] = coef2[M.elem_off + k];
     }
     for (int k = tid + (GCS > 7 ? 2 : 1) * nthr; k < ngc; k += nthr)
-      gc_l[k] = geo[(int64_t)elem_off * GCS + k];
+      gc_l[k] = geo[(int64_t)M.elem_off * GCS + k];
     // the round table (deterministic mode only) -> LDS, so the per-round element lookup is not a
     // global load that would drain the geometry prefetch queue (vmcnt retires in order)
     if (!ATOMIC)
       for (int k = tid; k < sh.nrounds * slots; k += nthr)
-        rt_l[k] = A.rounds[sh.rounds_off + k];
+        rt_l[k] = q->A.rounds[sh.rounds_off + k];
+  };
+
+  FUS_KARGS(q0);
+  const int blk_end = q0->A.blk_begin + q0->A.blk_count;
+  const int blk_stride = gridDim.x;
+  int blk = blockIdx.x + q0->A.blk_begin;
+  FUS_STAMP(blk, 0);
+  // first trip's geometry is requested before the block's dof values are staged
+  ElemIn<T, N, OP, GEOM, TD> inA, inB;
+  auto first_fetch = [&](KP q, const Meta& Mm) __attribute__((always_inline))
+  {
+    FUS_LANE_COORDS(q);
+    (void)b, (void)c, (void)sA, (void)sB;
+    const int slots = q->A.waves * EPW;
+    const int nt0 = ATOMIC ? (Mm.sh.nelem + slots - 1) / slots : Mm.sh.nrounds;
+    int e0 = -1;
+    if (active && nt0 > 0)
+      e0 = ATOMIC ? (myslot < Mm.sh.nelem ? myslot : -1) : (int)q->A.rounds[Mm.sh.rounds_off + myslot];
+    elem_fetch<T, N, OP, GEOM, TD>(inA, e0, q->geo, Mm.elem_off, p);
+  };
+  PLoad L;
+  {
+    const Meta M0 = meta_of(q0, blk);
+    first_fetch(q0, M0);
+    int gi0[US];
+    p_idx(q0, M0, true, gi0);
+    p_load(q0, M0, L, true, true, gi0);
   }
-
-  T* sA = scratch + (size_t)(wave * EPW + (active ? s : 0)) * (Nd + N);
-  T* sB = sA;  // single exchange tile per element slot
-
-  // lane-dependent rows/columns of the derivative table (tiny, cache resident)
+  bool first = true;
+  for (;;)
+  {
+  // ---- phase 1: this block's staged data -> LDS, then the element trips ----
+  FUS_KARGS(qc);
+  FUS_PHASE_LDS(qc);
+  FUS_LANE_COORDS(qc);
+  const Meta M = meta_of(qc, blk);
+  const ShapeDev& sh = M.sh;
+  const int elem_off = M.elem_off;
+  // element of this lane group in trip r: conflict-free round table (deterministic mode) or simply
+  // the next `slots` elements (atomic mode: no ordering constraint between waves)
+  const int ntrips = ATOMIC ? (sh.nelem + slots - 1) / slots : sh.nrounds;
+  auto elem_of = [&](int r) -> int
+  {
+    if (!active || r >= ntrips)
+      return -1;
+    if (ATOMIC)
+      return (r * slots + myslot < sh.nelem) ? r * slots + myslot : -1;
+    return (int)rt_l[r * slots + myslot];
+  };
+  p_commit(qc, M, L, first);
+  // the next block of this workgroup: its shared-dof indices are requested now and ride through the trips
+  // (degrees <= 4: a few registers), so that all of its prologue loads are independent in phase 2
+  const int blk_next = blk + blk_stride;
+  const bool has_next = blk_next < blk_end;
+  // (measured: requesting them here costs more than it saves -- the barrier ahead of the trips waits for
+  // them, 0.2525 -> 0.2620 ms at config 2 -- so the indices are read in phase 2)
+  constexpr bool IDX_EARLY = false;
+  int gi_n[US];
+  if constexpr (IDX_EARLY)
+  {
+    Meta Mi{};
+    if (has_next)
+      Mi = meta_of(qc, blk_next);
+    p_idx(qc, Mi, has_next, gi_n);
+  }
   __syncthreads();
   FUS_STAMP(blk, 1);
-  T Drb[N], Drc[N], Dcb[N], Dcc[N];
-#pragma unroll
-  for (int j = 0; j < N; ++j)
+  // lane-dependent rows/columns of the derivative table, quadrature weights and points of the lane's
+  // tensor column (the tables stay in LDS from the first block on)
+  T Drb[N], Drc[N], Dcb[N], Dcc[N], w3[N];
+  T wbc, pb, pc;
   {
-    constexpr bool inreg = (OP == OP_STIFFNESS) && !(FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) && P >= 6)
-                           && GEOM != GEOM_TRILINEAR && !(GEOM == GEOM_AFFINE && (P == 5 || P == 6));
-    Drb[j] = inreg ? D_l[b * N + j] : T(0);
-    Drc[j] = inreg ? D_l[c * N + j] : T(0);
-    Dcb[j] = inreg ? D_l[j * N + b] : T(0);
-    Dcc[j] = inreg ? D_l[j * N + c] : T(0);
-  }
-  T w3[N];  // w_q = w_a w_b w_c of this lane's points (affine geometry only)
 #pragma unroll
-  for (int a = 0; a < N; ++a)
-    w3[a] = (GEOM == GEOM_AFFINE) ? w_l[a] * w_l[b] * w_l[c] : T(0);
-  const T wbc = (GEOM == GEOM_TRILINEAR) ? w_l[b] * w_l[c] : T(0);
-  const T pb = (GEOM == GEOM_TRILINEAR) ? pt_l[b] : T(0), pc = (GEOM == GEOM_TRILINEAR) ? pt_l[c] : T(0);
+    for (int j = 0; j < N; ++j)
+    {
+      constexpr bool inreg = (OP == OP_STIFFNESS) && !(FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) && P >= 6)
+                             && GEOM != GEOM_TRILINEAR && !(GEOM == GEOM_AFFINE && (P == 5 || P == 6)) && !MF;
+      Drb[j] = inreg ? D_l[b * N + j] : T(0);
+      Drc[j] = inreg ? D_l[c * N + j] : T(0);
+      Dcb[j] = inreg ? D_l[j * N + b] : T(0);
+      Dcc[j] = inreg ? D_l[j * N + c] : T(0);
+    }
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      w3[a] = (GEOM == GEOM_AFFINE) ? w_l[a] * w_l[b] * w_l[c] : T(0);  // w_q = w_a w_b w_c of this lane's points
+    wbc = (GEOM == GEOM_TRILINEAR) ? w_l[b] * w_l[c] : T(0);
+    pb = (GEOM == GEOM_TRILINEAR) ? pt_l[b] : T(0), pc = (GEOM == GEOM_TRILINEAR) ? pt_l[c] : T(0);
+  }
 
   // ---- trips, two per iteration: while one register set is consumed the other is in flight ----
+  FUS_KARGS(qt);
+  DTab<T, N> Dk;   // derivative table, 1-D weights and points -> scalar registers for the trips
+#pragma unroll
+  for (int i = 0; i < N * N; ++i)
+    Dk.d[i] = qt->Dk.d[i];
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    Dk.w[i] = qt->Dk.w[i], Dk.x[i] = qt->Dk.x[i];
+  const T* __restrict__ geo = qt->geo;
 #define FUS_ELEM_COMPUTE(in)                                                                       \
   do                                                                                               \
   {                                                                                                \
-    if constexpr (TD == 3)                                                                         \
+    if constexpr (MF && TD == 3 && OP == OP_STIFFNESS)                                            \
+      elem_compute_mfma<T, N, ATOMIC, NF, GEOM>(in, Dk, x_l, y_l, sA, ldm_l, cf_l, x2_l, cf2_l,    \
+                                                gc_l, w3, D_l, wbc, pb, pc, p, lane);              \
+    else if constexpr (TD == 3)                                                                    \
       elem_compute<T, N, OP, ATOMIC, NF, GEOM>(in, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB,       \
                                                ldm_l, cf_l, x2_l, cf2_l, gc_l, w3, D_l, wbc, pb,   \
                                                pc, p, b, c);                                       \
@@ -1125,7 +1639,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
       FUS_STAMP(blk, 5);
     if (r == 2)
       FUS_STAMP(blk, 7);
-    if (!ATOMIC && A.waves > 1)
+    if (!ATOMIC && nwaves > 1)
       __syncthreads();
     elem_fetch<T, N, OP, GEOM, TD>(inA, elem_of(r + 2), geo, elem_off, p);
     if (has1)
@@ -1133,7 +1647,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
       FUS_ELEM_COMPUTE(inB);
       if (r == 0)
         FUS_STAMP(blk, 6);
-      if (!ATOMIC && A.waves > 1)
+      if (!ATOMIC && nwaves > 1)
         __syncthreads();
     }
   }
@@ -1141,8 +1655,34 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
   __syncthreads();
   FUS_STAMP(blk, 2);
 
+  // ---- phase 2: the next block of this workgroup -- its prologue loads travel while this block is
+  // written out ----
+  {
+    // (always executed, with every load predicated on has_next: the staged registers are then defined on
+    // every path and not live across the trips)
+    FUS_KARGS(qn);
+    Meta Mn{};
+    if (has_next)
+      Mn = meta_of(qn, blk_next);
+    if constexpr (!IDX_EARLY)
+      p_idx(qn, Mn, has_next, gi_n);
+    p_load(qn, Mn, L, false, has_next, gi_n);
+  }
+  {
+  // this block's epilogue operands (arguments, LDS carve and block data re-derived: see FUS_KARGS)
+  FUS_KARGS(qe);
+  FUS_PHASE_LDS(qe);
+  FUS_TID();
+  const Meta M = meta_of(qe, blk);
+  const ShapeDev& sh = M.sh;
+  const int int_off = M.int_off;
+  const int64_t sh_off = M.sh_off;
+  StageArgs<T> S;
+  load_stage_args<T, N>(qe, S);
+  T* __restrict__ bvec = qe->bvec;
+  T* __restrict__ partial = qe->partial;
+
   // ---- epilogue: each dof written once ----
-  typedef T V2 __attribute__((ext_vector_type(2)));
   const int nvec = sh.nint >> 1;
   if (STAGE == STAGE_NONE)
   {
@@ -1159,7 +1699,7 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
     const int k0 = S.blk_bnd_off[blk], k1 = S.blk_bnd_off[blk + 1];
     if (k1 > k0)
     {
-      const T* vstage = (STAGE == 0) ? S.v0 : S.vn;
+      const T* vstage = stage_is_first(STAGE) ? S.v0 : S.vn;
       for (int k = k0 + tid; k < k1; k += nthr)
       {
         const int gi = S.bnd_idx[k];
@@ -1170,76 +1710,60 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
       }
       __syncthreads();
     }
-    // fused stage update on the contiguous interior range (16-byte accesses); the scalar tail
-    // element of an odd range is handled by thread 0 with the same formulas
-    const int ntot = nvec + (sh.nint & 1);
+    // fused stage update on the contiguous interior range (16-byte accesses)
     // degrees <= 4, one operator input: two interior ranges per pass, the loads of both in flight before
     // the first store (+1-3 % on the per-cell geometry paths; with the second input's extra operands
     // -- Westervelt -- it measured 5 % slower, and the higher degrees were not measured)
     constexpr bool EPI2 = (P <= 4) && (NF == 1);
-    if constexpr (EPI2)
-    {
     struct Epi
     {
-      bool on, tail;
+      bool on;
       int i, o;
       V2 bv, mi, w, a0, b0, au, av, m1, m0v, us;
     };
     auto epi_load = [&](int i, Epi& E) __attribute__((always_inline))
     {
-      E.on = i < ntot;
-      if (!E.on)
-        return;
-      E.i = i, E.tail = i >= nvec, E.o = int_off + 2 * i;
-      auto ld = [&](const T* ptr) -> V2 {
-        V2 r;
-        if (!E.tail)
-          r = __builtin_nontemporal_load(reinterpret_cast<const V2*>(ptr + E.o));
-        else
-          r[0] = ptr[E.o], r[1] = T(0);
-        return r;
-      };
-      if (!E.tail)
-        E.bv = reinterpret_cast<const V2*>(y_l)[i];
-      else
-        E.bv[0] = y_l[2 * i], E.bv[1] = T(0);
+      // (every field is assigned on every path -- zeros where the range has ended -- so that none of them
+      // looks live across the block loop to the register allocator)
+      E.on = i < nvec;
+      E.i = i, E.o = int_off + 2 * i;
+      E.bv = E.mi = E.w = E.a0 = E.b0 = E.au = E.av = E.m1 = E.m0v = E.us = V2(T(0));
+      auto ld = [&](const T* ptr) -> V2
+      { return E.on ? __builtin_nontemporal_load(reinterpret_cast<const V2*>(ptr + E.o)) : V2(T(0)); };
+      auto lds = [&](const T* l) -> V2 { return E.on ? reinterpret_cast<const V2*>(l)[i] : V2(T(0)); };
+      E.bv = lds(y_l);
+      constexpr bool WV = NF == 2;   // Westervelt operands possible (S.mn1 decides at run time)
+      if ((WV && S.mn1) || STAGE == 4 || STAGE == 6)
+        E.us = lds(x_l);             // the stage input u_n of the interior dofs is still in LDS
       if (STAGE == 0)
         E.a0 = ld(S.u0), E.b0 = ld(S.v0);
+      else if (STAGE == 4)
+        E.a0 = E.us, E.b0 = ld(S.v0);
       else
         E.w = ld(S.vn);
-      if (NF == 2 && S.mn1)
-      {
-        if (!E.tail)
-          E.us = reinterpret_cast<const V2*>(x_l)[i];
-        else
-          E.us[0] = x_l[2 * i], E.us[1] = T(0);
+      if (WV && S.mn1)
         E.m1 = ld(S.mn1), E.m0v = ld(S.m0);
-      }
       else
         E.mi = ld(S.minv);
       if (STAGE == 3)
         E.au = ld(S.u_), E.av = ld(S.v_);
-      else if (STAGE != 0)
+      else if (STAGE == 1)
         E.au = ld(S.u_), E.av = ld(S.v_), E.a0 = ld(S.u0), E.b0 = ld(S.v0);
+      else if (STAGE == 5)
+        E.a0 = ld(S.u0), E.b0 = ld(S.v0);
+      else if (STAGE == 6)
+        E.av = ld(S.v_), E.a0 = ld(S.u0), E.b0 = ld(S.v0);
     };
     auto epi_store = [&](const Epi& E) __attribute__((always_inline))
     {
       if (!E.on)
         return;
-      auto st = [&](T* ptr, V2 val) {
-        if (!E.tail)
-          __builtin_nontemporal_store(val, reinterpret_cast<V2*>(ptr + E.o));
-        else
-          ptr[E.o] = val[0];
-      };
+      auto st = [&](T* ptr, V2 val) { __builtin_nontemporal_store(val, reinterpret_cast<V2*>(ptr + E.o)); };
       V2 kv;
       if (NF == 2 && S.mn1)
       {
-        const V2 vs = (STAGE == 0) ? E.b0 : E.w;
-        V2 den = E.m0v + E.m1 * E.us;
-        if (E.tail)
-          den[1] = T(1);
-        kv = (E.bv - E.m1 * vs * vs) / den;
+        const V2 vs = stage_is_first(STAGE) ? E.b0 : E.w;
+        kv = (E.bv - E.m1 * vs * vs) / (E.m0v + E.m1 * E.us);
       }
       else
         kv = E.bv * E.mi;
@@ -1250,10 +1774,28 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
         st(S.un, E.b0 * S.adt + E.a0);
         st(S.vn, kv * S.adt + E.b0);
       }
+      else if (STAGE == 4)
+      {
+        st(S.un, E.b0 * S.adt + E.a0);
+        st(S.vn, kv * S.adt + E.b0);
+      }
       else if (STAGE == 3)
       {
         st(S.u0, E.w * S.bdt + E.au);
         st(S.v0, kv * S.bdt + E.av);
+      }
+      else if (STAGE == 5)
+      {
+        st(S.v_, kv * S.bdt + ((E.w - E.b0) * S.r0 + E.b0));
+        st(S.un, E.w * S.adt + E.a0);
+        st(S.vn, kv * S.adt + E.b0);
+      }
+      else if (STAGE == 6)
+      {
+        st(S.u_, E.w * S.bdt + ((E.us - E.a0) * S.r1 + (E.b0 * S.b0dt + E.a0)));
+        st(S.v_, kv * S.bdt + E.av);
+        st(S.un, E.w * S.adt + E.a0);
+        st(S.vn, kv * S.adt + E.b0);
       }
       else
       {
@@ -1263,92 +1805,54 @@ k_block_op(const BlockArgs A, const DTab<T, P + 1> Dk, const T* __restrict__ Dg,
         st(S.vn, kv * S.adt + E.b0);
       }
     };
-    for (int i = tid; i < ntot; i += 2 * nthr)
+    // the last dof of an odd interior range: the one-dof form of the same update
+    if (tid == 0 && (sh.nint & 1))
+      (void)stage_update_dof<T, STAGE>((int64_t)int_off + sh.nint - 1, y_l[sh.nint - 1], S.minv, S.vn, S.un, S.u0,
+                                       S.v0, S.u_, S.v_, S.adt, S.bdt, (NF == 2) ? S.m0 : nullptr,
+                                       (NF == 2) ? S.mn1 : nullptr, LeanRK<T>{S.b0dt, S.r0, S.r1});
+    if constexpr (EPI2)
     {
-      Epi E0, E1;
-      epi_load(i, E0);
-      epi_load(i + nthr, E1);
-      epi_store(E0);
-      epi_store(E1);
-    }
+      for (int i = tid; i < nvec; i += 2 * nthr)
+      {
+        Epi E0, E1;
+        epi_load(i, E0);
+        epi_load(i + nthr, E1);
+        epi_store(E0);
+        epi_store(E1);
+      }
     }
     else
-    for (int i = tid; i < ntot; i += nthr)
     {
-      const bool tail = i >= nvec;
-      const int o = int_off + 2 * i;
-      V2 bv, mi, w, a0, b0, au, av;
-      auto ld = [&](const T* ptr) -> V2 {
-        V2 r;
-        if (!tail)  // read once per stage: keep these streams out of L2 / MALL
-          r = __builtin_nontemporal_load(reinterpret_cast<const V2*>(ptr + o));
-        else
-          r[0] = ptr[o], r[1] = T(0);
-        return r;
-      };
-      auto st = [&](T* ptr, V2 val) {
-        if (!tail)
-          __builtin_nontemporal_store(val, reinterpret_cast<V2*>(ptr + o));
-        else
-          ptr[o] = val[0];
-      };
-      if (!tail)
-        bv = reinterpret_cast<const V2*>(y_l)[i];
-      else
-        bv[0] = y_l[2 * i], bv[1] = T(0);
-      // stage inputs v_n (= v0 at stage 0) are needed by every variant below; load once
-      if (STAGE == 0)
-        a0 = ld(S.u0), b0 = ld(S.v0);
-      else
-        w = ld(S.vn);
-      V2 kv;
-      if (NF == 2 && S.mn1)
+      for (int i = tid; i < nvec; i += nthr)
       {
-        // Westervelt: kv = (b - mn1 v_n^2) / (m0 + mn1 u_n); u_n of interior dofs is still in x_l
-        const V2 vs = (STAGE == 0) ? b0 : w;
-        V2 us;
-        if (!tail)
-          us = reinterpret_cast<const V2*>(x_l)[i];
-        else
-          us[0] = x_l[2 * i], us[1] = T(0);
-        const V2 m1 = ld(S.mn1);
-        V2 den = ld(S.m0) + m1 * us;
-        if (tail)
-          den[1] = T(1);
-        kv = (bv - m1 * vs * vs) / den;
-      }
-      else
-      {
-        mi = ld(S.minv);
-        kv = bv * mi;
-      }
-      if (STAGE == 0)
-      {
-        st(S.u_, b0 * S.bdt + a0);
-        st(S.v_, kv * S.bdt + b0);
-        st(S.un, b0 * S.adt + a0);
-        st(S.vn, kv * S.adt + b0);
-      }
-      else if (STAGE == 3)
-      {
-        au = ld(S.u_), av = ld(S.v_);
-        st(S.u0, w * S.bdt + au);
-        st(S.v0, kv * S.bdt + av);
-      }
-      else
-      {
-        au = ld(S.u_), av = ld(S.v_), a0 = ld(S.u0), b0 = ld(S.v0);
-        st(S.u_, w * S.bdt + au);
-        st(S.v_, kv * S.bdt + av);
-        st(S.un, w * S.adt + a0);
-        st(S.vn, kv * S.adt + b0);
+        Epi E0;
+        epi_load(i, E0);
+        epi_store(E0);
       }
     }
   }
   for (int l = sh.nint + tid; l < sh.nloc; l += nthr)
     partial[sh_off + (l - sh.nint)] = y_l[l];
+  }
   FUS_TRACE_END(blk);
+  if (!has_next)
+    break;
+  __syncthreads();  // every wave has read what it needs of this block's x_l / y_l
+  blk = blk_next;
+  first = false;
+  {
+    // the next block's first trip: its element ids (and, streamed geometry, its factors)
+    FUS_KARGS(qf);
+    const Meta Mf = meta_of(qf, blk);
+    first_fetch(qf, Mf);
+  }
+  }
+#undef FUS_KARGS
+#undef FUS_LANE_COORDS
+#undef FUS_PHASE_LDS
+#undef FUS_TID
 }
+
 
 // bsh[s] = sum over the (block, slot) pairs of shared dof s, ascending block order (a trailing
 // pseudo pair carries the boundary term of a shared boundary dof, see k_boundary_partial)
@@ -1364,63 +1868,6 @@ __global__ void k_shared_reduce(int64_t s0, int64_t s1, const I* __restrict__ sh
   for (I k = sh_ptr[s]; k < sh_ptr[s + 1]; ++k)
     acc += partial[sh_pairs[k]];
   bsh[s] = acc;
-}
-
-// Fused RK4 stage update of ONE dof s whose right-hand side sum `acc` (= b) is complete.
-// kv = b * minv  (Linear.hpp:212-221), ku = vn (f0, :171-174).
-//   STAGE 0 : vn == v0, un == u0, u_ == u0, v_ == v0 (aliases are not read twice)
-//             u_ = u0 + bdt*v0 ; v_ = v0 + bdt*kv ; un' = u0 + adt*v0 ; vn' = v0 + adt*kv
-//   STAGE 1,2: u_ += bdt*vn ; v_ += bdt*kv ; un' = u0 + adt*vn ; vn' = v0 + adt*kv
-//   STAGE 3 : u0 = u_ + bdt*vn ; v0 = v_ + bdt*kv        (next step's state, no copies)
-// adt = dt*a_{i+1}, bdt = dt*b_i (Linear.hpp:282-294).
-//
-// Model vectors are read / written once per stage: non-temporal, so that the partial slab (written
-// just before by k_block_op) stays cache resident.
-template <typename T, int STAGE>
-__device__ __forceinline__ T stage_update_dof(int64_t s, T acc, const T* __restrict__ minv,
-                                                 T* __restrict__ vn, T* __restrict__ un,
-                                                 T* __restrict__ u0, T* __restrict__ v0,
-                                                 T* __restrict__ u_, T* __restrict__ v_, T adt, T bdt,
-                                                 const T* __restrict__ m0, const T* __restrict__ mn1)
-{
-#define FUS_LD(p) __builtin_nontemporal_load(&(p)[s])
-#define FUS_ST(p, val) __builtin_nontemporal_store((val), &(p)[s])
-  T kv;
-  if (mn1)  // Westervelt (see StageArgs): stage inputs u_n, v_n are u0, v0 at stage 0
-  {
-    const T us = (STAGE == 0) ? u0[s] : un[s], vs = (STAGE == 0) ? v0[s] : vn[s];
-    kv = (acc - mn1[s] * vs * vs) / (m0[s] + mn1[s] * us);
-  }
-  else
-    kv = acc * FUS_LD(minv);
-  T vnext;  // the velocity the NEXT stage starts from: vn' (stages 0-2) or the new v0 (stage 3)
-  if (STAGE == 0)
-  {
-    const T u = FUS_LD(u0), v = FUS_LD(v0);
-    FUS_ST(u_, v * bdt + u);
-    FUS_ST(v_, kv * bdt + v);
-    FUS_ST(un, v * adt + u);
-    vnext = kv * adt + v;
-    FUS_ST(vn, vnext);
-  }
-  else if (STAGE == 3)
-  {
-    FUS_ST(u0, FUS_LD(vn) * bdt + FUS_LD(u_));
-    vnext = kv * bdt + FUS_LD(v_);
-    FUS_ST(v0, vnext);
-  }
-  else
-  {
-    const T w = FUS_LD(vn);
-    FUS_ST(u_, w * bdt + FUS_LD(u_));
-    FUS_ST(v_, kv * bdt + FUS_LD(v_));
-    FUS_ST(un, w * adt + FUS_LD(u0));
-    vnext = kv * adt + FUS_LD(v0);
-    FUS_ST(vn, vnext);
-  }
-#undef FUS_LD
-#undef FUS_ST
-  return vnext;
 }
 
 // Boundary term of a shared boundary dof for the NEXT stage, produced where that dof's stage update
@@ -1461,7 +1908,7 @@ k_shared_stage(int64_t n, const int32_t* __restrict__ sh_ptr, const int32_t* __r
                const T* __restrict__ partial, const T* __restrict__ minv, T* __restrict__ vn,
                T* __restrict__ un, T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ u_,
                T* __restrict__ v_, T adt, T bdt, const T* __restrict__ m0,
-               const T* __restrict__ mn1, const BndNext<T> B)
+               const T* __restrict__ mn1, const BndNext<T> B, const LeanRK<T> R)
 {
   const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= n)
@@ -1473,7 +1920,7 @@ k_shared_stage(int64_t n, const int32_t* __restrict__ sh_ptr, const int32_t* __r
     pair = sh_pairs[k];
     acc += partial[pair];
   }
-  const T vnext = stage_update_dof<T, STAGE>(s, acc, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0, mn1);
+  const T vnext = stage_update_dof<T, STAGE>(s, acc, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0, mn1, R);
   boundary_next<T>(B, pair, vnext);
 }
 
@@ -1510,7 +1957,7 @@ k_if_unpack_stage(int64_t nu, const int32_t* __restrict__ uidx, const int32_t* _
                   T* __restrict__ un, T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ u_,
                   T* __restrict__ v_, T adt, T bdt, const T* __restrict__ m0,
                   const T* __restrict__ mn1, int64_t sh0, const int32_t* __restrict__ sh_ptr,
-                  const int32_t* __restrict__ sh_pairs, const BndNext<T> B)
+                  const int32_t* __restrict__ sh_pairs, const BndNext<T> B, const LeanRK<T> R)
 {
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= nu)
@@ -1523,7 +1970,7 @@ k_if_unpack_stage(int64_t nu, const int32_t* __restrict__ uidx, const int32_t* _
     const int32_t sidx = usrc[k];
     acc += (sidx < 0) ? own : recvbuf[sidx];
   }
-  const T vnext = stage_update_dof<T, STAGE>(u, acc, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0, mn1);
+  const T vnext = stage_update_dof<T, STAGE>(u, acc, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0, mn1, R);
   if (B.enabled)
     boundary_next<T>(B, sh_pairs[sh_ptr[u - sh0 + 1] - 1], vnext);
 }
@@ -1786,34 +2233,16 @@ __global__ void k_reciprocal(int64_t n, const T* __restrict__ m, T* __restrict__
     minv[i] = (m[i] != T(0)) ? T(1) / m[i] : T(0);
 }
 
-// Streaming triad y = x + a z with 16-byte accesses: the measured device bandwidth the roofline
-// fractions are also quoted against (fus_measure_bandwidth).
+// Streaming copy y = x with 16-byte non-temporal accesses, one vector per thread (a flat grid: on MI355X
+// this form reaches the device's copy bandwidth, 6.3-6.6 TB/s, where grid-stride loops over a few thousand
+// workgroups stay at 4.4-5.4 TB/s -- tools/bw_probe.hip): the measured streaming bandwidth beside the
+// roofline fractions (fus_measure_bandwidth).
 template <typename V>  // V = 2 doubles as an ext_vector (a template only so that every unit may include it)
-__global__ void __launch_bounds__(256) k_triad(int64_t nvec, const V* __restrict__ x,
-                                               const V* __restrict__ z, V* __restrict__ y, double a)
+__global__ void __launch_bounds__(256) k_stream_copy(int64_t nvec, const V* __restrict__ x, V* __restrict__ y)
 {
-  constexpr int U = 4;  // independent 16-byte loads per array in flight per thread
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  for (; i + (U - 1) * stride < nvec; i += U * stride)
-  {
-    V xv[U], zv[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-    {
-      xv[u] = __builtin_nontemporal_load(x + i + u * stride);
-      zv[u] = __builtin_nontemporal_load(z + i + u * stride);
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u)
-    {
-      __builtin_nontemporal_store(xv[u] + a * zv[u], y + i + u * stride);
-    }
-  }
-  for (; i < nvec; i += stride)
-  {
-    y[i] = x[i] + a * z[i];
-  }
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < nvec)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(x + i), y + i);
 }
 
 // halo helpers

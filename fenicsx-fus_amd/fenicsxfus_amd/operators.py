@@ -122,6 +122,9 @@ class SpectralOperatorData:
     def geometry_mode(self) -> str:
         return ("stream", "affine", "trilinear")[lib().fus_op_geometry_mode(self.h)]
 
+    def uses_mfma(self) -> bool:
+        return bool(lib().fus_op_uses_mfma(self.h))
+
     def facet_diag(self, cells, local_facets, cellcoef):
         cells = np.ascontiguousarray(cells, dtype=np.int32)
         lf = np.ascontiguousarray(local_facets, dtype=np.int32)

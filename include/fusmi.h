@@ -154,6 +154,9 @@ int fus_op_is_affine(fus_op* op);
  * hexahedra with the Jacobian recomputed per point from the cell's trilinear map (21 numbers per
  * cell; the default for first-order meshes with non-affine cells). */
 int fus_op_geometry_mode(fus_op* op);
+/* 1 when the operator's block kernel runs its index-1 / index-2 contractions on the matrix cores
+ * (MFMA 16x16x4; degrees 6 and 7 on the per-cell geometry paths, option "mfma"). */
+int fus_op_uses_mfma(fus_op* op);
 /* Smallest cell size of the local mesh, the size of a cell being its largest vertex-to-vertex
  * distance (dolfinx::mesh::h, linear_planewave2d_1/main.cpp:60-64); dt = CFL hmin / (c P^2), :102. */
 int fus_op_hmin(fus_op* op, double* hmin);
@@ -255,8 +258,9 @@ int fus_model_stage_end(fus_model* model, int stage, double t, double dt);
  * kernels, so timed runs use 2 (bench.py) and take the full breakdown in a separate pass. */
 int fus_profile_enable(fus_ctx* ctx, int on);
 int fus_profile_get(fus_ctx* ctx, const char* name, double* total_ms, int64_t* count);
-/* Measured streaming bandwidth of the device (triad y = x + a z over three arrays of nbytes each,
- * best of reps launches, GB/s): the number the roofline fractions are also quoted against. */
+/* Measured streaming bandwidth of the device (16-byte non-temporal copy of nbytes, one vector per
+ * thread; bytes read + bytes written per second, best of reps launches, GB/s): reported beside the
+ * roofline fractions. */
 int fus_measure_bandwidth(fus_ctx* ctx, int64_t nbytes, int reps, double* gbps);
 
 /* Host-only layout builder (no device needed): runs the block partitioner / DOF renumbering on

@@ -171,6 +171,46 @@ def _linear_setup(orc, ctx, n, P, hi, perturb=0.0, c0=1500.0, rho0=1000.0, heter
     return pr, c, rho, tags
 
 
+@pytest.mark.parametrize("model_kind", ["linear", "westervelt"])
+def test_rk4_accumulator_streams_kept_or_rebuilt(orc, model_kind):
+    """Option "lean_rk4" (default 1): stages 0-2 of the classical RK4 do not keep the accumulators u_, v_
+    in HBM but rebuild them from vectors the later stages read anyway (kernels.hpp, stage kinds 4-6);
+    0 streams them at every stage like Linear.hpp:282-294.  Both against the oracle, and against each
+    other to rounding, on interior, shared and boundary dofs (16 blocks)."""
+    L, P, n, nsteps = 0.012, 4, (6, 6, 6), 20
+    pr, c, rho, tags = _linear_setup(orc, None, n, P, [L, L, L], perturb=0.1, hetero=True)
+    dt = 0.5 * (L / n[0]) / (c.max() * P**2)
+    tf = nsteps * dt * (1 - 1e-9)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    if model_kind == "linear":
+        m, src, absb, coeff = pr.linear_model_vectors(c, rho, tags)
+        orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, 0.5e6, 6e4, 1500.0, 0.0, tf, dt, u, v)
+    else:
+        delta = np.full(pr.mesh.num_cells, fa.compute_diffusivity_of_sound(2 * np.pi * 0.5e6, 1500.0, 0.2))
+        beta = np.full(pr.mesh.num_cells, 3.5)
+        m, src, absb, src2, lin, att = pr.lossy_model_vectors(c, rho, delta, tags)
+        n1 = -2.0 * beta / rho**2 / c**4
+        orc.westervelt_rk4(3, pr.N, pr.dm, pr.G, pr.detJ, pr.D, lin, att, n1, -n1, m, src, absb, src2, 0.5e6, 6e6, 1500.0,
+                           0.0, tf, dt, u, v)
+    sols = []
+    for lean in (1, 0):
+        cx = fa.Context(0, block_elems=16)
+        cx.set_option("lean_rk4", lean)
+        if model_kind == "linear":
+            model = fa.LinearSpectralExplicit(pr.mesh, tags, P, c, rho, 0.5e6, 6e4, 1500.0, 4, dt, V=pr.V, ctx=cx)
+        else:
+            model = fa.WesterveltSpectralExplicit(pr.mesh, tags, P, c, rho, delta, beta, 0.5e6, 6e6, 1500.0, 4, dt,
+                                                  V=pr.V, ctx=cx)
+        model.init()
+        un, vn, _ = model.rk(0.0, tf)
+        assert np.abs(u).max() > 0
+        assert relmax(un.x.array, u) < TOL_RK and relmax(vn.x.array, v) < TOL_RK
+        sols.append((un.x.array.copy(), vn.x.array.copy()))
+        model.close()
+        cx.close()
+    assert relmax(sols[0][0], sols[1][0]) < 1e-13 and relmax(sols[0][1], sols[1][1]) < 1e-13
+
+
 @pytest.mark.parametrize("hetero,perturb", [(False, 0.0), (True, 0.1)])
 def test_linear_rk4_vs_oracle(orc, ctx, hetero, perturb):
     L = 0.012
@@ -607,3 +647,44 @@ def test_graph_replay_of_the_rk_step(orc, tdim):
     # 25 full steps (+ a ~1e-12 dt remainder step, far below the tolerance)
     orc.linear_rk4(tdim, pr.N, pr.dm, pr.G, pr.D, coeff, mv, src, absb, 0.5e6, 6e4, 1500.0, 0.0, 25 * dt * (1 + 1e-12), dt, u, v)
     assert relmax(res[1][0], u) < TOL_RK
+
+
+@pytest.mark.parametrize("geometry,perturb", [("trilinear", 0.15), ("auto", 0.0), ("stream", 0.15)])
+@pytest.mark.parametrize("walk", [1, 2])
+def test_walking_workgroups(orc, geometry, perturb, walk):
+    """Option "walk": `walk` workgroups per CU, each walking every (walk * CUs)-th block with the next block's
+    prologue loads in flight under the current block's epilogue.  A mesh with more blocks than workgroups
+    (4-element blocks) so that workgroups really walk 2-4 blocks, of different shapes: operator actions and
+    the RK4 loop against the oracle, and bit-identical to one workgroup per block in deterministic mode."""
+    P, n, L = 4, (16, 12, 12), 0.012
+    pr, c, rho, tags = _linear_setup(orc, None, n, P, [L * 4 / 3, L, L], perturb=perturb, hetero=True)
+    rng = np.random.default_rng(5)
+    x, coef = rng.standard_normal(pr.ndofs), rng.uniform(0.5, 2.0, pr.mesh.num_cells)
+    refK, refM = pr.K(x, coef), pr.M(x, coef)
+    outs = {}
+    for w in (walk, 0):
+        cx = fa.Context(0, geometry=geometry, block_elems=4, deterministic=1)
+        cx.set_option("walk", w)
+        d = fa.SpectralOperatorData(pr.V, cx)
+        assert d.info()["nblocks"] == 576
+        y = d.stiffness(x, coef, np.zeros(pr.ndofs))
+        ym = d.mass(x, coef, np.zeros(pr.ndofs))
+        assert relmax(y, refK) < TOL_OP and relmax(ym, refM) < 1e-13
+        outs[w] = (y, ym)
+        d.close()
+        cx.close()
+    if geometry != "stream":      # (the streamed-geometry kernel keeps one workgroup per block)
+        assert np.array_equal(outs[walk][0], outs[0][0]) and np.array_equal(outs[walk][1], outs[0][1])
+    dt = 0.5 * (L / 12) / (c.max() * P**2)
+    nsteps = 6
+    m, src, absb, coeff = pr.linear_model_vectors(c, rho, tags)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, 0.5e6, 6e4, 1500.0, 0.0, nsteps * dt * (1 - 1e-9), dt, u, v)
+    cx = fa.Context(0, geometry=geometry, block_elems=4)
+    cx.set_option("walk", walk)
+    model = fa.LinearSpectralExplicit(pr.mesh, tags, P, c, rho, 0.5e6, 6e4, 1500.0, 4, dt, V=pr.V, ctx=cx)
+    model.init()
+    un, vn, _ = model.rk(0.0, nsteps * dt * (1 - 1e-9))
+    assert np.abs(u).max() > 0 and relmax(un.x.array, u) < TOL_RK and relmax(vn.x.array, v) < TOL_RK
+    model.close()
+    cx.close()

@@ -16,7 +16,7 @@ OUT = os.path.join(HERE, "fenicsxfus_amd", "libfusmi.so")
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-function",
          "-munsafe-fp-atomics"]
-DEGREES = (2, 3, 4, 5, 6, 7)
+DEGREES = (2, 3, 4, 5, 6, 7, 8, 9, 10)
 
 
 def _compile_units(objdir, degrees, extra, verbose):

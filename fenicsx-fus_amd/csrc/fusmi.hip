@@ -174,8 +174,8 @@ struct fus_ctx
   // index-1 / index-2 contractions of the degrees 6 and 7 on the matrix cores (per-cell geometry kernels):
   // -1 auto (the measured choice per degree, scalar type and geometry), 0 never, 1 wherever a variant exists
   int mfma = -1;
-  int walk = -1;  // block-kernel workgroups per CU that walk several blocks each (0: one workgroup per block,
-                  // -1: auto), see launch_block_op_v
+  int walk = 0;   // block-kernel workgroups per CU that walk several blocks each (0: one workgroup per block --
+                  // the measured best everywhere so far; -1: as many as are resident), see launch_block_op_v
 };
 
 struct Neigh
@@ -351,13 +351,16 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
   K.S = S;
   // option "walk" = w > 0: w workgroups per CU, each walking every (w * CUs)-th block of the range with
   // the next block's prologue loads in flight under the current block's epilogue (per-cell geometry
-  // kernels; the streamed-geometry kernel keeps one workgroup per block)
+  // kernels; the streamed-geometry kernel keeps one workgroup per block).  Off by default: measured on
+  // MI355X (config 2, profiles/r02_experiments.md) one workgroup per block is 13-17 % faster -- the
+  // hardware's own dispatch of a fresh workgroup into a freed slot overlaps the phases of different
+  // blocks better than the walking workgroup's software pipeline does.
   int grid = blk_count;
   if (GEOM != GEOM_STREAM && TD == 3 && op->ctx->walk != 0)
   {
     int per_cu = op->ctx->walk;
-    if (per_cu < 0)  // auto: as many workgroups per CU as are resident at once (measured best: 2 eight-wave /
-    {                // 4 four-wave blocks at degree 4), where a workgroup then has at least 4 blocks to walk
+    if (per_cu < 0)  // as many workgroups per CU as are resident at once, where each then has >= 4 blocks to walk
+    {
       static int occ[2] = {-1, -1};  // per instantiation; [0]: this LDS size
       static size_t occ_lds = 0;
       if (occ[0] < 0 || occ_lds != op->lds_bytes)
@@ -368,7 +371,7 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
             op->lds_bytes));
         occ[0] = std::max(nb, 1), occ_lds = op->lds_bytes;
       }
-      per_cu = (P == 4 && sizeof(T) == 8 && blk_count >= 4 * occ[0] * op->ctx->num_cus) ? occ[0] : 0;
+      per_cu = (blk_count >= 4 * occ[0] * op->ctx->num_cus) ? occ[0] : 0;
     }
     if (per_cu > 0)
       grid = std::min(blk_count, per_cu * op->ctx->num_cus);
@@ -389,6 +392,22 @@ static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, 
   if (blk_count < 0)
     blk_count = op->L.nblocks - blk_begin;
   const int b0 = blk_begin, nb = blk_count;
+  if constexpr (P >= 8)
+  {
+    // degrees 8-10: two waves per element (kernels.hpp, elem_compute_hi), per-cell geometry only
+    if (op->tdim != 3 || !(op->affine || op->trilinear))
+      return fail(FUS_ERR_ARG, "degrees 8-10: first-order hexahedra (affine or trilinear geometry path) only");
+    const T* gc = static_cast<const T*>(op->d_Gc);
+    if (op->affine)
+      return op->deterministic
+                 ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_AFFINE>(op, gc, coef, x, bvec, S, b0, nb)
+                 : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_AFFINE>(op, gc, coef, x, bvec, S, b0, nb);
+    return op->deterministic
+               ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_TRILINEAR>(op, gc, coef, x, bvec, S, b0, nb)
+               : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_TRILINEAR>(op, gc, coef, x, bvec, S, b0, nb);
+  }
+  else
+  {
   if (op->tdim == 2)  // quadrilaterals: streamed geometry only
     return op->deterministic
                ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_STREAM, 2>(op, geo, coef, x, bvec, S, b0, nb)
@@ -396,7 +415,7 @@ static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, 
   // degrees 6 and 7, per-cell geometry, LDS-atomic accumulation: the index-1 / index-2 contractions on the
   // matrix cores (kernels.hpp, elem_compute_mfma) where option "mfma" / the measured default says so; the
   // variants exist for the stiffness operator as the plain action and as the lean RK4 stages
-  if constexpr (P >= 6 && OP == OP_STIFFNESS && (STAGE == STAGE_NONE || STAGE >= 3))
+  if constexpr ((P == 6 || P == 7) && OP == OP_STIFFNESS && (STAGE == STAGE_NONE || STAGE >= 3))
   {
     if (op->mfma && !op->deterministic && op->tdim == 3 && (op->affine || op->trilinear))
     {
@@ -423,6 +442,7 @@ static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, 
   return op->deterministic
              ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_STREAM>(op, geo, coef, x, bvec, S, b0, nb)
              : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_STREAM>(op, geo, coef, x, bvec, S, b0, nb);
+  }
 }
 
 template <typename T>
@@ -595,8 +615,11 @@ static int ensure_stream_geometry(fus_op* op)
 // index-1 / index-2 contractions.
 static bool mfma_default(int P, bool f64, bool affine)
 {
-  (void)P, (void)f64, (void)affine;
-  return false;
+  // degree 7, fp64, trilinear geometry: block kernel 1.62 -> 1.53 ms per launch at 64^3 (-5.8 %; the vector
+  // ALUs, busy with the per-point Jacobians, are what the matrix cores relieve).  Slower everywhere else:
+  // affine geometry at degree 7 (+6 %: its vector work is small), fp32 at degree 6 (+45 %: the f32 MFMA
+  // issues at the vector rate and half of every 16 x 16 x 4 tile is padding).
+  return P == 7 && f64 && !affine;
 }
 
 template <typename T, int P>
@@ -1442,11 +1465,13 @@ static const DegreeImpl* degree_impl(int dtype, int P)
 }
 #else
 FUS_DECL_DEGREE(2) FUS_DECL_DEGREE(3) FUS_DECL_DEGREE(4) FUS_DECL_DEGREE(5) FUS_DECL_DEGREE(6) FUS_DECL_DEGREE(7)
+FUS_DECL_DEGREE(8) FUS_DECL_DEGREE(9) FUS_DECL_DEGREE(10)
 static const DegreeImpl* degree_impl(int dtype, int P)
 {
   switch (P)
   {
     FUS_CASE_DEGREE(2) FUS_CASE_DEGREE(3) FUS_CASE_DEGREE(4) FUS_CASE_DEGREE(5) FUS_CASE_DEGREE(6) FUS_CASE_DEGREE(7)
+    FUS_CASE_DEGREE(8) FUS_CASE_DEGREE(9) FUS_CASE_DEGREE(10)
   default: return nullptr;
   }
 }
@@ -1454,7 +1479,7 @@ static const DegreeImpl* degree_impl(int dtype, int P)
 #define FUS_DEGREE(d, dtype_, P_)                                                                  \
   const DegreeImpl* d = degree_impl(dtype_, P_);                                                   \
   if (!d)                                                                                          \
-    return fail(FUS_ERR_ARG, "unsupported polynomial degree (2..7)");
+    return fail(FUS_ERR_ARG, "unsupported polynomial degree (2..10)");
 
 static int d_op_setup(fus_op* op)
 {
@@ -1608,6 +1633,34 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   // elements at P = 2 / 3 / >= 4; larger P shrink further to fit LDS), half of that on the affine
   // path (profiles/r01_block_sweep.txt)
   // quadrilaterals: N^2 nodes per element, so many more elements make a block of that size
+  if (op->P >= 8)
+  {
+    // degrees 8-10 (two waves per element): 4-element blocks, an even number of waves
+    const bool aff = affine_mesh;
+    int waves8 = c->waves > 0 ? std::min(4, (c->waves + 1) & ~1) : 4;
+    for (int be = c->block_elems > 0 ? c->block_elems : 4;; be = (be + 1) / 2)
+    {
+      std::string err = build_layout(op->L, op->P, op->ncells, op->ndofs, op->h_dofmap.data(), cen.data(), be, waves8,
+                                     force_shared, op->tdim);
+      const bool too_big = err.empty() ? op->L.lds_bytes(op->ts, op->nfields, aff ? 7 : 21) + 64 > 160 * 1024
+                                       : err.find("65535") != std::string::npos;
+      if (too_big && be > 1)
+        continue;
+      if (!err.empty())
+        return fail(FUS_ERR_ARG, "layout: " + err);
+      if (too_big)
+        return fail(FUS_ERR_LIMIT, "a one-element block does not fit the LDS budget at this degree");
+      break;
+    }
+    int r8 = d_op_setup(op);
+    if (r8 != FUS_OK)
+    {
+      for (void* q : op->allocs)
+        (void)hipFree(q);
+      op->allocs.clear();
+    }
+    return r8;
+  }
   static const int be_quad[8] = {0, 0, 512, 256, 256, 128, 128, 64};
   // fp32 halves the LDS per dof: there the best sizes keep two or three blocks per CU resident
   // (p=4: 48, p=5/6: 24, p=7: 16 -- +8 / +15 / +45 / +42 % over 32 elements, profiles/r01_block_sweep.txt)
@@ -1958,12 +2011,15 @@ int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_
     return fail(FUS_ERR_ARG, "null argument");
   if (tdim != 2 && tdim != 3)
     return fail(FUS_ERR_ARG, "tdim must be 3 (hexahedra) or 2 (quadrilaterals)");
-  if (P < 2 || P > 7)
-    return fail(FUS_ERR_ARG, "unsupported polynomial degree (2..7)");
+  if (P < 2 || P > 10)
+    return fail(FUS_ERR_ARG, "unsupported polynomial degree (2..10)");
   if (dtype != FUS_F64 && dtype != FUS_F32)
     return fail(FUS_ERR_ARG, "dtype must be FUS_F32 or FUS_F64");
   if (geom_order != 1 && geom_order != 2)
     return fail(FUS_ERR_ARG, "geometry order must be 1 (2^tdim vertices) or 2 (3^tdim nodes, tensor order)");
+  if (P >= 8 && (tdim != 3 || geom_order != 1 || c->geometry == 1))
+    return fail(FUS_ERR_ARG, "degrees 8-10: first-order hexahedra through the per-cell geometry kernels (option "
+                             "\"geometry\" 0 or 2) only");
   if (ncells <= 0 || ndofs <= 0 || nnodes <= 0)
     return fail(FUS_ERR_ARG, "empty mesh");
   const int N = P + 1;

@@ -665,6 +665,167 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 }
 
 // ---------------------------------------------------------------------------------------------
+// Degrees 8-10 (N = 9, 10, 11; the reference's Qdegree map goes to P = 10, spectral_op.hpp:35-44): a tensor
+// plane has more than 64 columns, so an element is worked on by TWO waves (lane pair index p = 0..127,
+// columns p < N^2), the exchanges through the element's LDS tile are fenced by workgroup barriers instead
+// of wave barriers, and nothing returns early (every wave of the workgroup meets every barrier; `on` guards
+// the memory operations of lanes without an element or a column).  Tile-read form of the index-1 / index-2
+// contractions with the derivative table read from LDS; per-cell geometry (affine / trilinear).
+template <typename T, int N, int OP, int ATOMIC, int NF, int GEOM>
+__device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTab<T, N>& Dk, const T* __restrict__ x_l,
+                                                T* __restrict__ y_l, T* __restrict__ sA,
+                                                const uint16_t* __restrict__ ldm_l, const T* __restrict__ cf_l,
+                                                const T* __restrict__ x2_l, const T* __restrict__ cf2_l,
+                                                const T* __restrict__ gc_l, const T* __restrict__ D_l,
+                                                const T* __restrict__ w_l, const T* __restrict__ pt_l, int p, int b,
+                                                int c)
+{
+  static_assert(GEOM == GEOM_AFFINE || GEOM == GEOM_TRILINEAR, "per-cell geometry kernels");
+  constexpr int N2 = N * N, Nd = N * N * N;
+  const bool on = er_ >= 0 && has_col;
+  const int er = er_ >= 0 ? er_ : 0;
+  const int pp = has_col ? p : 0, bb = has_col ? b : 0, cc = has_col ? c : 0;
+  TriLane<T> tri;
+  T wbc = T(0);
+  if (GEOM == GEOM_TRILINEAR)
+  {
+    tri.init(gc_l + er * 21, pt_l[bb], pt_l[cc]);
+    wbc = w_l[bb] * w_l[cc];
+  }
+  int li[N];
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    li[a] = on ? (int)ldm_l[er * Nd + a * N2 + pp] : 0;
+  const T cf = (NF == 2) ? T(1) : cf_l[er];
+  T Y[N];
+  if (OP == OP_STIFFNESS)
+  {
+    T X[N], F0[N], F1[N], F2[N];
+    if (NF == 2)
+    {
+      const T c1 = cf_l[er], c2 = cf2_l[er];
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        X[a] = c1 * x_l[li[a]] + c2 * x2_l[li[a]];
+    }
+    else
+    {
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        X[a] = x_l[li[a]];
+    }
+    // derivative along tensor index 0: registers only (spectral_op.hpp:194-196)
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+    {
+      T acc = T(0);
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        acc += Dk.d[q * N + i] * X[i];
+      F0[q] = acc;
+    }
+    if (on)
+    {
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        sA[a * N2 + pp] = X[a];
+    }
+    __syncthreads();
+    // derivatives along tensor indices 1 and 2 (spectral_op.hpp:199-210)
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      T f1 = T(0), f2 = T(0);
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+      {
+        f1 += D_l[bb * N + j] * sA[a * N2 + j * N + cc];
+        f2 += D_l[cc * N + j] * sA[a * N2 + bb * N + j];
+      }
+      F1[a] = f1;
+      F2[a] = f2;
+    }
+    // stiffness::transform (spectral_op.hpp:113-130)
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      if (GEOM == GEOM_TRILINEAR)
+        tri.transform(Dk.x[a], Dk.w[a] * wbc * cf, F0[a], F1[a], F2[a]);
+      else
+      {
+        const T w3 = w_l[a] * w_l[bb] * w_l[cc];
+        T G6[6];
+#pragma unroll
+        for (int gi = 0; gi < 6; ++gi)
+          G6[gi] = gc_l[er * 7 + gi] * w3;   // affine cell: G(q) = Gc w_q
+        const T w0 = F0[a], w1 = F1[a], w2 = F2[a];
+        F0[a] = cf * (G6[0] * w0 + G6[1] * w1 + G6[2] * w2);
+        F1[a] = cf * (G6[1] * w0 + G6[3] * w1 + G6[4] * w2);
+        F2[a] = cf * (G6[2] * w0 + G6[4] * w1 + G6[5] * w2);
+      }
+    }
+    // transposed contractions (spectral_op.hpp:222-238)
+    __syncthreads();
+    if (on)
+    {
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        sA[a * N2 + pp] = F1[a];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      T acc = T(0);
+#pragma unroll
+      for (int q = 0; q < N; ++q)
+        acc += Dk.d[q * N + a] * F0[q];
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        acc += D_l[j * N + bb] * sA[a * N2 + j * N + cc];
+      Y[a] = acc;
+    }
+    __syncthreads();
+    if (on)
+    {
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        sA[a * N2 + pp] = F2[a];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      T acc = Y[a];
+#pragma unroll
+      for (int j = 0; j < N; ++j)
+        acc += D_l[j * N + cc] * sA[a * N2 + bb * N + j];
+      Y[a] = acc;
+    }
+    __syncthreads();   // the tile is free for the next element
+  }
+  else
+  {
+    // mass::transform (spectral_op.hpp:19-26)
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      Y[a] = cf * x_l[li[a]]
+             * (GEOM == GEOM_TRILINEAR ? tri.detw(Dk.x[a], Dk.w[a] * wbc) : gc_l[er * 7 + 6] * (w_l[a] * w_l[bb] * w_l[cc]));
+  }
+  if (on)
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      if (ATOMIC)
+        __hip_atomic_fetch_add(&y_l[li[a]], Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      else
+        y_l[li[a]] += Y[a];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // MFMA contraction path (degrees 6 and 7, per-cell geometry kernels; template parameter MF of k_block_op).
 // At N = 7, 8 one element fills a wave, and each of the index-1 / index-2 contractions of an element is an
 // (N x N) . (N x N^2) product -- the reference's contract<T, N, N, N, N, bool>
@@ -705,14 +866,27 @@ struct MfmaOp<float>
   static __device__ __forceinline__ int row(int g, int r) { return 4 * g + r; }
 };
 
-// One directional contraction of the element in the tile: out[.., q, ..] = sum_k A[q][k] in[.., k, ..]
-// with the contracted index at stride SK and the free index at stride SF inside a plane of N^2 values.
+// Position of tensor entry (a, b, c) in the element's LDS tile.  N = 8: the fastest index is XOR-swizzled
+// with bits of the other two, c ^ (2 (b >> 2) | 4 (a & 1)), which keeps the lane-per-column accesses
+// (a fixed, lanes (b, c)) conflict-free and spreads the operand reads of the index-2 contraction (lanes
+// (b, c = k) for two planes a) over the banks -- 4-way conflicts otherwise (57 % of the LDS cycles of the
+// unswizzled form were bank conflicts: profiles/r02_mfma.md).
+template <int N>
+__device__ __forceinline__ int mfma_tix(int a, int b, int c)
+{
+  if constexpr (N == 8)
+    return a * 64 + b * 8 + (c ^ (((b >> 2) << 1) | ((a & 1) << 2)));
+  else
+    return (a * N + b) * N + c;
+}
+
+// One directional contraction of the element in the tile: out[.., q, ..] = sum_k A[q][k] in[.., k, ..];
+// DIR = 1: the contracted index is tensor index 1 (free index 2 on the columns), DIR = 2: the reverse.
 // Bm[t][s]: this lane's B operands (read from the tile by the caller before it is overwritten).
-template <typename T, int N, int SK, int SF>
+template <typename T, int N, int DIR>
 __device__ __forceinline__ void mfma_tile_contract(const T (&Am)[2], const T (&Bm)[4][2], T* __restrict__ sA, int g,
                                                    int ha, int hc)
 {
-  constexpr int N2 = N * N;
   typedef typename MfmaOp<T>::V4 V4;
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -727,15 +901,14 @@ __device__ __forceinline__ void mfma_tile_contract(const T (&Am)[2], const T (&B
     {
       const int q = MfmaOp<T>::row(g, r);
       if (q < N && a < N && hc < N)
-        sA[a * N2 + q * SK + hc * SF] = acc[r];
+        sA[DIR == 1 ? mfma_tix<N>(a, q, hc) : mfma_tix<N>(a, hc, q)] = acc[r];
     }
   }
 }
 
-template <typename T, int N, int SK, int SF>
+template <typename T, int N, int DIR>
 __device__ __forceinline__ void mfma_tile_operands(T (&Bm)[4][2], const T* __restrict__ sA, int g, int ha, int hc)
 {
-  constexpr int N2 = N * N;
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -743,7 +916,8 @@ __device__ __forceinline__ void mfma_tile_operands(T (&Bm)[4][2], const T* __res
     {
       const int a = 2 * t + ha, k = 4 * s + g;
       // padding (N = 7) reads a valid, finite tile entry; its table entry is zero
-      Bm[t][s] = sA[(a < N && k < N && hc < N) ? a * N2 + k * SK + hc * SF : 0];
+      const bool ok = a < N && k < N && hc < N;
+      Bm[t][s] = sA[ok ? (DIR == 1 ? mfma_tix<N>(a, k, hc) : mfma_tix<N>(a, hc, k)) : 0];
     }
 }
 
@@ -766,6 +940,7 @@ __device__ __forceinline__ void elem_compute_mfma(const ElemIn<T, N, OP_STIFFNES
     return;
   const bool on = in.er >= 0;
   const int g = lane >> 4, h = lane & 15, ha = h >> 3, hc = h & 7;
+  const int pb_i = on ? p / N : 0, pc_i = on ? p - (p / N) * N : 0;   // the lane's tensor column (b, c)
   T Af[2], At[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s)
@@ -811,30 +986,30 @@ __device__ __forceinline__ void elem_compute_mfma(const ElemIn<T, N, OP_STIFFNES
   {
 #pragma unroll
     for (int a = 0; a < N; ++a)
-      sA[a * N2 + p] = X[a];
+      sA[mfma_tix<N>(a, pb_i, pc_i)] = X[a];
   }
   FUS_WAVE_SYNC();
   // derivatives along tensor indices 1 and 2 (spectral_op.hpp:199-210) on the matrix cores
   T B1[4][2], B2[4][2];
-  mfma_tile_operands<T, N, N, 1>(B1, sA, g, ha, hc);   // contracted index 1 (stride N), free index 2
-  mfma_tile_operands<T, N, 1, N>(B2, sA, g, ha, hc);   // contracted index 2 (stride 1), free index 1
+  mfma_tile_operands<T, N, 1>(B1, sA, g, ha, hc);   // contracted index 1 (stride N), free index 2
+  mfma_tile_operands<T, N, 2>(B2, sA, g, ha, hc);   // contracted index 2 (stride 1), free index 1
   FUS_WAVE_SYNC();
-  mfma_tile_contract<T, N, N, 1>(Af, B1, sA, g, ha, hc);
+  mfma_tile_contract<T, N, 1>(Af, B1, sA, g, ha, hc);
   FUS_WAVE_SYNC();
   if (on)
   {
 #pragma unroll
     for (int a = 0; a < N; ++a)
-      F1[a] = sA[a * N2 + p];
+      F1[a] = sA[mfma_tix<N>(a, pb_i, pc_i)];
   }
   FUS_WAVE_SYNC();
-  mfma_tile_contract<T, N, 1, N>(Af, B2, sA, g, ha, hc);
+  mfma_tile_contract<T, N, 2>(Af, B2, sA, g, ha, hc);
   FUS_WAVE_SYNC();
   if (on)
   {
 #pragma unroll
     for (int a = 0; a < N; ++a)
-      F2[a] = sA[a * N2 + p];
+      F2[a] = sA[mfma_tix<N>(a, pb_i, pc_i)];
   }
   // stiffness::transform (spectral_op.hpp:113-130)
   if (on)
@@ -863,19 +1038,19 @@ __device__ __forceinline__ void elem_compute_mfma(const ElemIn<T, N, OP_STIFFNES
   {
 #pragma unroll
     for (int a = 0; a < N; ++a)
-      sA[a * N2 + p] = F1[a];
+      sA[mfma_tix<N>(a, pb_i, pc_i)] = F1[a];
   }
   FUS_WAVE_SYNC();
-  mfma_tile_operands<T, N, N, 1>(B1, sA, g, ha, hc);
+  mfma_tile_operands<T, N, 1>(B1, sA, g, ha, hc);
   FUS_WAVE_SYNC();
-  mfma_tile_contract<T, N, N, 1>(At, B1, sA, g, ha, hc);
+  mfma_tile_contract<T, N, 1>(At, B1, sA, g, ha, hc);
   FUS_WAVE_SYNC();
   if (on)
   {
 #pragma unroll
     for (int a = 0; a < N; ++a)
     {
-      T acc = sA[a * N2 + p];
+      T acc = sA[mfma_tix<N>(a, pb_i, pc_i)];
 #pragma unroll
       for (int q = 0; q < N; ++q)
         acc += Dk.d[q * N + a] * F0[q];
@@ -887,19 +1062,19 @@ __device__ __forceinline__ void elem_compute_mfma(const ElemIn<T, N, OP_STIFFNES
   {
 #pragma unroll
     for (int a = 0; a < N; ++a)
-      sA[a * N2 + p] = F2[a];
+      sA[mfma_tix<N>(a, pb_i, pc_i)] = F2[a];
   }
   FUS_WAVE_SYNC();
-  mfma_tile_operands<T, N, 1, N>(B2, sA, g, ha, hc);
+  mfma_tile_operands<T, N, 2>(B2, sA, g, ha, hc);
   FUS_WAVE_SYNC();
-  mfma_tile_contract<T, N, 1, N>(At, B2, sA, g, ha, hc);
+  mfma_tile_contract<T, N, 2>(At, B2, sA, g, ha, hc);
   FUS_WAVE_SYNC();
   if (on)
   {
 #pragma unroll
     for (int a = 0; a < N; ++a)
     {
-      Y[a] += sA[a * N2 + p];
+      Y[a] += sA[mfma_tix<N>(a, pb_i, pc_i)];
       if (ATOMIC)
         __hip_atomic_fetch_add(&y_l[li[a]], Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       else
@@ -1196,7 +1371,7 @@ __device__ __forceinline__ void load_stage_args(const KArgs<T, N> __attribute__(
 // derivative-table rows read from LDS where used.
 // TD = 2: the same block machinery for quadrilateral elements (Nd = N^2, GEOM_STREAM only).
 template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3, int MF = 0>
-__global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P <= 4 && GEOM == GEOM_AFFINE)
+__global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P >= 8) ? 1 : (P <= 4 && GEOM == GEOM_AFFINE)
                                                             ? 4
                                                             : ((GEOM == GEOM_TRILINEAR || (GEOM == GEOM_AFFINE && P <= 6)) ? FUS_TRI_WAVES(P) : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1)))
 k_block_op(const KArgs<T, P + 1> kernel_args)
@@ -1204,6 +1379,11 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   static_assert(TD == 3 || GEOM == GEOM_STREAM, "quadrilaterals use the streamed geometry");
   constexpr int N = P + 1, N2 = N * N, Nd = (TD == 3) ? N * N * N : N * N;
   constexpr int EPW = (64 / N2) > 0 ? (64 / N2) : 1;
+  // lanes that work on one element slot group: a wave, or two waves where a tensor plane has more than
+  // 64 columns (degrees 8-10, elem_compute_hi)
+  constexpr int LPE = (N2 <= 64) ? 64 : 128;
+  static_assert(N2 <= 128, "degrees up to 10");
+  static_assert(LPE == 64 || (TD == 3 && GEOM != GEOM_STREAM && !MF), "degrees 8-10: hexahedra, per-cell geometry");
 
   (void)kernel_args;
   // Kernel arguments are read from the kernarg segment where they are used, through a pointer that is
@@ -1220,18 +1400,18 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   // block loop in scalar registers)
 #define FUS_PHASE_LDS(q)                                                                           \
   const int lds_nloc = q->A.lds_nloc, lds_nelem = q->A.lds_nelem, nwaves = q->A.waves;             \
-  const int slots = nwaves * EPW;                                                                  \
+  const int slots = (nwaves * 64 / LPE) * EPW;                                                     \
   T* x_l = reinterpret_cast<T*>(smem_raw);                                                         \
   T* y_l = x_l + lds_nloc;                                                                         \
   T* x2_l = y_l + lds_nloc; /* second input (NF == 2 only) */                                      \
   T* scratch = x2_l + (NF == 2 ? lds_nloc : 0);                                                    \
-  T* D_l = scratch + (size_t)nwaves * EPW * (Nd + N); /* derivative table (tiles: Nd + N each) */  \
+  T* D_l = scratch + (size_t)slots * (Nd + N); /* derivative table (tiles: Nd + N each) */         \
   T* cf_l = D_l + N2; /* per-element coefficient(s) */                                             \
   T* cf2_l = cf_l + lds_nelem;                                                                     \
   T* gc_l = cf2_l + (NF == 2 ? lds_nelem : 0); /* affine: 6 G + 1 detJ; trilinear: 21 map coefficients */ \
-  T* w_l = gc_l + GCS * lds_nelem; /* 1-D weights (8 slots), 1-D points (8 slots) */               \
-  T* pt_l = w_l + 8;                                                                               \
-  uint16_t* ldm_l = reinterpret_cast<uint16_t*>(w_l + (GCS ? 16 : 0)); /* 16-B aligned */          \
+  T* w_l = gc_l + GCS * lds_nelem; /* 1-D weights, 1-D points: 8 slots each (12: degrees 8-10) */  \
+  T* pt_l = w_l + (N <= 8 ? 8 : 12);                                                               \
+  uint16_t* ldm_l = reinterpret_cast<uint16_t*>(w_l + (GCS ? (N <= 8 ? 16 : 24) : 0)); /* 16-B aligned */ \
   int16_t* rt_l = reinterpret_cast<int16_t*>(ldm_l + (size_t)lds_nelem * Nd);                      \
   (void)y_l, (void)x2_l, (void)scratch, (void)D_l, (void)cf_l, (void)cf2_l, (void)gc_l, (void)w_l, (void)pt_l,      \
       (void)ldm_l, (void)rt_l, (void)slots
@@ -1247,7 +1427,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   // workgroup and kept live (and spilled) across its prologue / epilogue phases
 #define FUS_LANE_COORDS(q)                                                                         \
   FUS_TID();                                                                                       \
-  const int lane = tid & 63, wave = tid >> 6;                                                    \
+  const int lane = tid % LPE, wave = tid / LPE; /* a wave, or a wave pair (degrees 8-10) */        \
   const int s = lane / N2, p = lane - s * N2;                                                      \
   const int b = p / N, c = p - b * N;                                                              \
   const bool active = s < EPW;                                                                     \
@@ -1515,7 +1695,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   {
     FUS_LANE_COORDS(q);
     (void)b, (void)c, (void)sA, (void)sB;
-    const int slots = q->A.waves * EPW;
+    const int slots = (q->A.waves * 64 / LPE) * EPW;
     const int nt0 = ATOMIC ? (Mm.sh.nelem + slots - 1) / slots : Mm.sh.nrounds;
     int e0 = -1;
     if (active && nt0 > 0)
@@ -1604,7 +1784,10 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
 #define FUS_ELEM_COMPUTE(in)                                                                       \
   do                                                                                               \
   {                                                                                                \
-    if constexpr (MF && TD == 3 && OP == OP_STIFFNESS)                                            \
+    if constexpr (LPE == 128)                                                                      \
+      elem_compute_hi<T, N, OP, ATOMIC, NF, GEOM>(in.er, s == 0, Dk, x_l, y_l, sA, ldm_l, cf_l,    \
+                                                  x2_l, cf2_l, gc_l, D_l, w_l, pt_l, p, b, c);     \
+    else if constexpr (MF && TD == 3 && OP == OP_STIFFNESS)                                        \
       elem_compute_mfma<T, N, ATOMIC, NF, GEOM>(in, Dk, x_l, y_l, sA, ldm_l, cf_l, x2_l, cf2_l,    \
                                                 gc_l, w3, D_l, wbc, pb, pc, p, lane);              \
     else if constexpr (TD == 3)                                                                    \

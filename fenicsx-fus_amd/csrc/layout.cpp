@@ -68,7 +68,8 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
   L.ncells = ncells, L.ndofs = ndofs;
   L.waves = std::max(1, waves);
   L.epw = std::max(1, 64 / (L.N * L.N));
-  L.slots = L.waves * L.epw;
+  // degrees 8-10 on hexahedra: a tensor plane has more than 64 columns and two waves share an element
+  L.slots = (tdim == 3 && L.N * L.N > 64) ? std::max(1, L.waves / 2) : L.waves * L.epw;
   const int Nd = L.Nd;
   if (block_elems < 1)
     block_elems = 64;

@@ -39,9 +39,30 @@ QUAD_FACET_VERTS = np.array([[0, 1], [0, 2], [1, 3], [2, 3]])
 VTK_QUAD9_TO_TENSOR = np.array([0, 4, 1, 7, 8, 5, 3, 6, 2])
 
 
+def _vtk_hex27_to_tensor():
+    """27-node (triquadratic) hexahedron: XDMF ``Hexahedron_27`` files written by DOLFINx / meshio list the
+    nodes in VTK order -- 8 corners (VTK hexahedron order), 12 mid-edge nodes (edges 0-1, 1-2, 2-3, 3-0,
+    4-5, 5-6, 6-7, 7-4, 0-4, 1-5, 2-6, 3-7), 6 face centres (x-, x+, y-, y+, z-, z+) and the body centre
+    (DOLFINx ``io::cells::perm_vtk``); libfusmi takes them in tensor order n = nx + 3 ny + 9 nz.
+    Returns perm with tensor[k] = vtk[perm[k]]."""
+    corner = [(0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1)]
+    edges = [(0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7)]
+    pos = [tuple(2 * c for c in v) for v in corner]
+    pos += [tuple(corner[a][d] + corner[b][d] for d in range(3)) for a, b in edges]
+    pos += [(0, 1, 1), (2, 1, 1), (1, 0, 1), (1, 2, 1), (1, 1, 0), (1, 1, 2), (1, 1, 1)]
+    perm = np.empty(27, dtype=np.int64)
+    for i, (nx, ny, nz) in enumerate(pos):
+        perm[nx + 3 * ny + 9 * nz] = i
+    return perm
+
+
+VTK_HEX27_TO_TENSOR = _vtk_hex27_to_tensor()
+
+
 class HexMesh:
-    """Unstructured first-order hexahedral mesh with the attributes the adapter reads from a
-    DOLFINx mesh (``geometry.x``, ``geometry.dofmap``, ``topology.dim``, ``index_map``)."""
+    """Unstructured hexahedral mesh, first-order (8 vertices, tensor order v = vx + 2 vy + 4 vz) or
+    second-order (27 nodes, tensor order n = nx + 3 ny + 9 nz), with the attributes the adapter reads from
+    a DOLFINx mesh (``geometry.x``, ``geometry.dofmap``, ``topology.dim``, ``index_map``)."""
 
     tdim = 3
     _facet_verts = FACET_VERTS
@@ -54,7 +75,6 @@ class HexMesh:
         cells = np.ascontiguousarray(cells, dtype=np.int32)
         self.order = 1 if cells.shape[1] == (1 << self.tdim) else 2
         assert x.shape[1] == 3 and cells.shape[1] == (self.order + 1) ** self.tdim
-        assert self.order == 1 or self.tdim == 2, "second-order cells: quadrilaterals only"
         # positions of the 2^tdim corner vertices (v = vx + 2 vy + 4 vz) inside a cell's node list
         g = self.order + 1
         self._corners = np.array([sum((((v >> d) & 1) * self.order) * g**d for d in range(self.tdim))
@@ -182,6 +202,10 @@ def read_xdmf_mesh(xdmf_path: str, name: str | None = None, dtype=np.float64):
     files = {}
 
     def data(item):
+        if item.get("Format", "HDF").upper() == "XML":          # values inline in the XDMF file
+            dims = [int(k) for k in item.get("Dimensions").split()]
+            kind = item.get("NumberType", item.get("DataType", "Float")).lower()
+            return np.array(item.text.split(), dtype=np.float64 if kind == "float" else np.int64).reshape(dims)
         fname, dset = item.text.strip().split(":")
         if fname not in files:
             files[fname] = H5File(os.path.join(base, fname))
@@ -196,8 +220,10 @@ def read_xdmf_mesh(xdmf_path: str, name: str | None = None, dtype=np.float64):
         mesh = QuadMesh(x, data(topo.find("DataItem"))[:, VTK_QUAD_TO_TENSOR], dtype=dtype)
     elif kind == "quadrilateral_9":
         mesh = QuadMesh(x, data(topo.find("DataItem"))[:, VTK_QUAD9_TO_TENSOR], dtype=dtype)
+    elif kind == "hexahedron_27":
+        mesh = HexMesh(x, data(topo.find("DataItem"))[:, VTK_HEX27_TO_TENSOR], dtype=dtype)
     else:
-        raise NotImplementedError("grids read: first-order hexahedra, first- and second-order quadrilaterals")
+        raise NotImplementedError("grids read: first- and second-order hexahedra and quadrilaterals")
     cell_vals, ftags = None, None
     g = grids.get(f"{name}_cells")
     if g is not None:

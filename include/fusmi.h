@@ -71,6 +71,17 @@ int fus_synchronize(fus_ctx* ctx);
  * "graph" (1: on one rank the launches of an RK step are captured and replayed as one hipGraph, the
  * executable graph being updated in place with each step's stage scalars; for launch-bound sizes
  * such as BASELINE config 1; default 0).
+ * "lean_rk4" (set before fus_model_create; default 1): stages 0-2 of the classical RK4 do not stream the
+ * accumulators u_, v_ of Linear.hpp:282-294 -- stages 1 and 2 rebuild them from vectors they read anyway
+ * (240 instead of 296 bytes of vector traffic per DOF and step, same arithmetic up to rounding); 0 keeps
+ * them in HBM at every stage.  The Runge-Kutta orders 1-3 always keep them.
+ * "mfma" (-1 auto (default) | 0 | 1, before fus_op_create): degrees 6 and 7 on the per-cell geometry
+ * paths -- the index-1 / index-2 contractions of an element, the (N x N).(N x N^2) products of the
+ * reference's contract<> (sum_factorisation.hpp:70-86), as 16x16x4 MFMA tiles on the matrix cores
+ * instead of vector FMAs.  Auto = where it measured faster on MI355X (degree 7, fp64, trilinear geometry).
+ * "walk" (0 (default) | 1..8 | -1, any time): block-kernel workgroups per CU that walk several blocks each
+ * with the next block's prologue loads in flight under the current block's epilogue; 0 = one workgroup
+ * per block (measured faster everywhere so far, profiles/r02_experiments.md), -1 = as many as are resident.
  * Unknown keys -> FUS_ERR_ARG. */
 int fus_set_option(fus_ctx* ctx, const char* key, int64_t value);
 
@@ -113,7 +124,9 @@ int fus_comm_init_local(fus_ctx** ctxs, int n);
  *               geom_dofmap int32[ncells * 4] with v = vx + 2vy (order 1) or int32[ncells * 9] with
  *               n = nx + 3ny (order 2, biquadratic), G has 3 entries (xx, xy, yy) per point, local
  *               facets 0..3 = y=0, x=0, x=1, y=1)
- *   P           polynomial degree 2..7; N = P+1 nodes per direction
+ *   P           polynomial degree 2..10 (the reference's Qdegree map, spectral_op.hpp:35-44); N = P+1 nodes per
+ *               direction.  Degrees 8-10: first-order hexahedra through the per-cell geometry paths only
+ *               ("geometry" 0 or 2); a tensor plane then has more than 64 columns and two waves share an element
  *   dtype       FUS_F64 | FUS_F32: type of geom_x and of every vector/coefficient argument later
  *   tensor_dofmap  int32[ncells * N^tdim], local DOF indices < ndofs, x-slowest tensor order
  *   nodes1d     double[N]

@@ -460,7 +460,7 @@ def test_edge_cases_and_errors(orc, ctx):
     nodes = np.ascontiguousarray(pr.V.nodes1d)
     args = lambda P, dt, order, nd: (ctx.h, 3, P, dt, C.c_int64(1), C.c_int64(pr.ndofs), _abi.ptr(dm), _abi.ptr(nd),  # noqa
                                      _abi.ptr(xg), C.c_int64(len(xg)), _abi.ptr(gd), order, C.byref(op))
-    assert L.fus_op_create(*args(9, 1, 1, nodes)) == -1 and b"degree" in L.fus_last_error()
+    assert L.fus_op_create(*args(11, 1, 1, nodes)) == -1 and b"degree" in L.fus_last_error()   # the map ends at 10
     assert L.fus_op_create(*args(3, 7, 1, nodes)) == -1
     assert L.fus_op_create(*args(3, 1, 2, nodes)) == -1 and b"geometry" in L.fus_last_error()
     bad = nodes.copy()

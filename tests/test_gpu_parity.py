@@ -395,7 +395,7 @@ def test_full_size_properties(orc, ctx):
     assert abs(mm.sum() - L**3) < 1e-12 * L**3
     info = d.info()
     if d.geometry_mode() == "affine":      # affine default: 16-element blocks
-        assert info["nblocks"] == 262144 // 16 and info["shapes"] == 27
+        assert info["nblocks"] == 262144 // 32 and info["shapes"] == 27
     else:                                  # streamed factors: 32-element blocks
         assert d.geometry_mode() == "stream" and info["nblocks"] == 262144 // 32
     d.close()

@@ -260,6 +260,8 @@ def main():
     ap.add_argument("--mfma", type=int, default=None, choices=[-1, 0, 1],
                     help="degrees 6 and 7: index-1 / index-2 contractions on the matrix cores (1), on the vector ALUs (0), "
                          "or the library's measured default (-1)")
+    ap.add_argument("--pack32", type=int, default=None, choices=[-1, 0, 1],
+                    help="fp32 degrees 5-7: two elements per wave in packed float2 (1), scalar kernel (0), library default (-1)")
     ap.add_argument("--walk", type=int, default=None,
                     help="block-kernel workgroups per CU that walk several blocks each (0: one workgroup per block)")
     ap.add_argument("--lean-rk4", type=int, default=None, choices=[0, 1],
@@ -319,7 +321,7 @@ def main():
         if args.global_cells:
             tail += ["--global-cells", str(args.global_cells)]
         for k, v in (("--block-elems", args.block_elems), ("--waves", args.waves), ("--deterministic", args.deterministic),
-                     ("--mfma", args.mfma), ("--lean-rk4", args.lean_rk4), ("--walk", args.walk)):
+                     ("--mfma", args.mfma), ("--lean-rk4", args.lean_rk4), ("--walk", args.walk), ("--pack32", args.pack32)):
             if v is not None:
                 tail += [k, str(v)]
         traffic, traffic_src = live_traffic(tail, args.P, args.dtype)
@@ -337,7 +339,7 @@ def main():
     ctx = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves, deterministic=args.deterministic, geometry=args.geometry)
     if args.graph is not None:
         ctx.set_option("graph", args.graph)
-    for key, val in (("mfma", args.mfma), ("lean_rk4", args.lean_rk4), ("walk", args.walk)):
+    for key, val in (("mfma", args.mfma), ("lean_rk4", args.lean_rk4), ("walk", args.walk), ("pack32", args.pack32)):
         if val is not None:
             ctx.set_option(key, val)
     transport = args.transport
@@ -422,6 +424,7 @@ def main():
         model.init()
         info = model.data.info()
         info["mfma"] = model.data.uses_mfma()
+        info["pack32"] = model.data.uses_pack32()
         affine = model.data.geometry_mode()        # "stream" | "affine" | "trilinear"
         advance(0.0, warmup)
         done = warmup
@@ -559,7 +562,7 @@ def main():
                        "medium": args.medium,
                        "partition": "middle x-slab of 3, exchange looped back (diagnostic)" if args.halo_loopback
                        else f"x-slabs x{world}", "transport": transport if (world > 1 or args.halo_loopback) else "none",
-                       "blocks": info["nblocks"], "mfma_contractions": mfma_used,
+                       "blocks": info["nblocks"], "mfma_contractions": mfma_used, "packed_fp32": bool(info.get("pack32")),
                        "lds_bytes_per_block": info["lds_bytes"], "dt": dt},
             # the timed K-step block repeated: value / ms_per_step are the median repeat
             "repeats": {"n": len(times), "ms_per_step": ms_rep, "min": min(ms_rep), "max": max(ms_rep),

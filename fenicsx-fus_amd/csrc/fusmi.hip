@@ -174,6 +174,7 @@ struct fus_ctx
   // index-1 / index-2 contractions of the degrees 6 and 7 on the matrix cores (per-cell geometry kernels):
   // -1 auto (the measured choice per degree, scalar type and geometry), 0 never, 1 wherever a variant exists
   int mfma = -1;
+  int pack32 = -1;  // fp32, degrees 5-7, per-cell geometry: two elements per wave in packed float2 (-1 auto, 0, 1)
   int walk = 0;   // block-kernel workgroups per CU that walk several blocks each (0: one workgroup per block --
                   // the measured best everywhere so far; -1: as many as are resident), see launch_block_op_v
 };
@@ -211,6 +212,7 @@ struct fus_op
   bool affine = false;     // GEOM_AFFINE path in use (d_Gc), streamed G/detJ built only on demand
   bool trilinear = false;  // GEOM_TRILINEAR path in use (d_Gc holds 21 map coefficients per cell)
   bool mfma = false;       // MFMA contraction variants of the block kernel in use (degrees 6, 7)
+  bool pk = false;         // packed fp32 variants in use (degrees 5-7: two elements per wave, layout slots doubled)
   void* d_Gc = nullptr;
   void *d_xg = nullptr, *d_pts = nullptr, *d_wts = nullptr;
   int32_t* d_xdm = nullptr;
@@ -321,7 +323,7 @@ struct ProfScope
 // -------------------------------------------------------------------------------------------------
 // typed implementation
 // -------------------------------------------------------------------------------------------------
-template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3, int MF = 0>
+template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3, int MF = 0, int PK = 0>
 static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x, T* bvec,
                              const StageArgs<T>& S, int blk_begin, int blk_count)
 {
@@ -339,7 +341,7 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
   const uint64_t dev_bit = 1ull << (op->ctx->device & 63);
   if (!(attr_set.load(std::memory_order_relaxed) & dev_bit))
   {
-    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD, MF>),
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD, MF, PK>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
   }
@@ -367,7 +369,7 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
       {
         int nb = 0;
         HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nb, reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD, MF>), 64 * op->L.waves,
+            &nb, reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD, MF, PK>), 64 * op->L.waves,
             op->lds_bytes));
         occ[0] = std::max(nb, 1), occ_lds = op->lds_bytes;
       }
@@ -376,7 +378,7 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
     if (per_cu > 0)
       grid = std::min(blk_count, per_cu * op->ctx->num_cus);
   }
-  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD, MF>), dim3(grid),
+  hipLaunchKernelGGL((k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD, MF, PK>), dim3(grid),
                      dim3(64 * op->L.waves), op->lds_bytes, op->ctx->stream, K);
   HIPCHK(hipGetLastError());
   return FUS_OK;
@@ -422,6 +424,17 @@ static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, 
       const T* gc = static_cast<const T*>(op->d_Gc);
       return op->affine ? launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_AFFINE, 3, 1>(op, gc, coef, x, bvec, S, b0, nb)
                         : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_TRILINEAR, 3, 1>(op, gc, coef, x, bvec, S, b0, nb);
+    }
+  }
+  // fp32, degrees 5-7, per-cell geometry, LDS-atomic accumulation: two elements per wave in packed float2
+  // (kernels.hpp, elem_compute_pk); stiffness operator only (the mass action runs through the scalar kernel)
+  if constexpr (sizeof(T) == 4 && P >= 5 && P <= 7 && OP == OP_STIFFNESS)
+  {
+    if (op->pk && !op->mfma && !op->deterministic && op->tdim == 3 && (op->affine || op->trilinear))
+    {
+      const T* gc = static_cast<const T*>(op->d_Gc);
+      return op->affine ? launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_AFFINE, 3, 0, 1>(op, gc, coef, x, bvec, S, b0, nb)
+                        : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_TRILINEAR, 3, 0, 1>(op, gc, coef, x, bvec, S, b0, nb);
     }
   }
   // geometry operand: per-cell factors (affine meshes) or the streamed per-point arrays
@@ -1684,6 +1697,12 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   const int be_affine = (op->tdim == 3 && op->P >= 5) ? ((op->dtype == FUS_F32 && op->P == 5) ? 16 : be_aff_hi[op->P])
                                                       : be_stream / 2;
   const int gcs = affine_mesh ? 7 : (trilinear_mesh ? 21 : 0);
+  // packed fp32 kernels (two elements per wave): degrees 5-7, per-cell geometry, LDS atomics, MFMA variants off
+  // "auto" = where it measured faster on MI355X (profiles/r02_experiments.md section 7): degree 5 (+4 %) and degree 6
+  // on affine cells (+2 %); slower at degree 6 trilinear (-12 %: 137 registers, three waves per SIMD) and degree 7
+  op->pk = op->dtype == FUS_F32 && op->tdim == 3 && op->P >= 5 && op->P <= 7 && (affine_mesh || trilinear_mesh)
+           && !c->deterministic && c->mfma != 1
+           && (c->pack32 == 1 || (c->pack32 < 0 && (op->P == 5 || (op->P == 6 && affine_mesh))));
   // fp32 halves the LDS per block: the trilinear kernel takes 16 elements at p >= 5 (+9-12 %), the
   // affine one at p = 5 only (+5 %; 16 is 2-9 % slower at p = 6, 7)
   const bool hi32 = op->dtype == FUS_F32 && op->tdim == 3 && op->P >= 5;
@@ -1708,7 +1727,7 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   for (int be = be0;; be = two_per_cu && be > 4 ? be - std::max(1, be / 4) : (be + 1) / 2)
   {
     std::string err = build_layout(op->L, op->P, op->ncells, op->ndofs, op->h_dofmap.data(),
-                                   cen.data(), be, waves, force_shared, op->tdim);
+                                   cen.data(), be, waves, force_shared, op->tdim, op->pk ? 2 : 1);
     const bool too_big = err.empty() ? op->L.lds_bytes(op->ts, op->nfields, gcs) + 64 > lds_cap
                                      : err.find("65535") != std::string::npos;
     if (too_big && be > 1)
@@ -1827,6 +1846,12 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
   }
   else if (!strcmp(key, "lean_rk4"))
     c->lean_rk4 = value != 0;
+  else if (!strcmp(key, "pack32"))
+  {
+    if (value < -1 || value > 1)
+      return fail(FUS_ERR_ARG, "pack32 must be -1 (auto), 0 or 1");
+    c->pack32 = (int)value;
+  }
   else if (!strcmp(key, "walk"))
   {
     if (value < -1 || value > 8)
@@ -2143,6 +2168,7 @@ static void layout_info(const Layout& L, size_t ts, int64_t out[8])
 int fus_op_is_affine(fus_op* op) { return (op && op->affine) ? 1 : 0; }
 int fus_op_geometry_mode(fus_op* op) { return !op ? 0 : (op->affine ? 1 : (op->trilinear ? 2 : 0)); }
 int fus_op_uses_mfma(fus_op* op) { return (op && op->mfma) ? 1 : 0; }
+int fus_op_uses_pack32(fus_op* op) { return (op && op->pk && !op->mfma) ? 1 : 0; }
 
 int fus_op_info(fus_op* op, int64_t out[8])
 {

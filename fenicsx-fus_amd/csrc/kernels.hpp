@@ -826,6 +826,242 @@ __device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTa
 }
 
 // ---------------------------------------------------------------------------------------------
+// Packed fp32 path (template parameter PK of k_block_op; degrees 5-7, per-cell geometry kernels).
+// In fp32 the scalar kernels issue as many LDS and vector instructions per element as the fp64 ones while
+// each moves half the bytes -- counters show fp32 p=6 bound by the LDS pipe (profiles/r02_experiments.md
+// section 2).  Here a wave works on TWO elements at once: lane (b, c) holds float2 = (element A, element B)
+// of its tensor column, every exchange through the tile is one 8-byte access for both, and the arithmetic
+// is packed (v_pk_fma_f32), so LDS and vector instructions per element halve.  Same algorithm as the
+// re-mapped form of elem_compute (spectral_op.hpp:194-238); the gather and scatter stay per element.
+typedef float F2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ F2 pk_rcp(F2 x)
+{
+  F2 r = {__builtin_amdgcn_rcpf(x[0]), __builtin_amdgcn_rcpf(x[1])};
+  r = (F2(1.0f) - x * r) * r + r;
+  return r;
+}
+__device__ __forceinline__ F2 pk_abs(F2 x) { return F2{__builtin_fabsf(x[0]), __builtin_fabsf(x[1])}; }
+
+template <int N, int ATOMIC, int NF, int GEOM>
+__device__ __forceinline__ void elem_compute_pk(int e0, int e1, const DTab<float, N>& Dk, const float* __restrict__ x_l,
+                                                float* __restrict__ y_l, F2* __restrict__ sA,
+                                                const uint16_t* __restrict__ ldm_l, const float* __restrict__ cf_l,
+                                                const float* __restrict__ x2_l, const float* __restrict__ cf2_l,
+                                                const float* __restrict__ gc_l, const float* __restrict__ w_l,
+                                                const float* __restrict__ pt_l, int p, int b, int c)
+{
+  static_assert(GEOM == GEOM_AFFINE || GEOM == GEOM_TRILINEAR, "per-cell geometry kernels");
+  constexpr int N2 = N * N, Nd = N * N * N;
+  constexpr int TS = (N == 8 || N == 4) ? N2 + 1 : N2;   // plane stride of the tile (see elem_compute, REMAP)
+  if (e0 < 0)
+    return;
+  const bool two = e1 >= 0;
+  const int eb = two ? e1 : e0;   // a lone element is computed twice, scattered once
+  int li0[N], li1[N];
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+  {
+    li0[a] = ldm_l[e0 * Nd + a * N2 + p];
+    li1[a] = ldm_l[eb * Nd + a * N2 + p];
+  }
+  const F2 cf = (NF == 2) ? F2(1.0f) : F2{cf_l[e0], cf_l[eb]};
+  F2 X[N], F0[N], F1[N], F2v[N], Y[N];
+  if (NF == 2)
+  {
+    const F2 c1 = {cf_l[e0], cf_l[eb]}, c2 = {cf2_l[e0], cf2_l[eb]};
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      X[a] = c1 * F2{x_l[li0[a]], x_l[li1[a]]} + c2 * F2{x2_l[li0[a]], x2_l[li1[a]]};
+  }
+  else
+  {
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      X[a] = F2{x_l[li0[a]], x_l[li1[a]]};
+  }
+  // index 0: registers
+#pragma unroll
+  for (int q = 0; q < N; ++q)
+  {
+    F2 acc = F2(0.0f);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      acc += Dk.d[q * N + i] * X[i];
+    F0[q] = acc;
+  }
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    sA[a * TS + p] = X[a];
+  FUS_WAVE_SYNC();
+  F2 Tb[N], Uc[N];
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+  {
+    Tb[k] = sA[b * TS + k * N + c];
+    Uc[k] = sA[b * TS + c * N + k];
+  }
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int q = 0; q < N; ++q)
+  {
+    F2 acc = F2(0.0f);
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      acc += Dk.d[q * N + k] * Tb[k];
+    sA[b * TS + q * N + c] = acc;  // d/dX1 at point (b, q, c)
+  }
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    F1[a] = sA[a * TS + p];
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int q = 0; q < N; ++q)
+  {
+    F2 acc = F2(0.0f);
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+      acc += Dk.d[q * N + k] * Uc[k];
+    sA[b * TS + c * N + q] = acc;  // d/dX2 at point (b, c, q)
+  }
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    F2v[a] = sA[a * TS + p];
+  // stiffness::transform (spectral_op.hpp:113-130), both elements at once
+  if (GEOM == GEOM_TRILINEAR)
+  {
+    // the lane-constant parts of the two cells' Jacobians (TriLane, packed)
+    const float pb = pt_l[b], pc = pt_l[c];
+    const F2 wbc = F2(w_l[b] * w_l[c]) * cf;
+    F2 j0[3], a1[3], d1[3], a2[3], d2[3];
+    const float* ca = gc_l + e0 * 21;
+    const float* cb = gc_l + eb * 21;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+      const F2 c100 = {ca[i], cb[i]}, c010 = {ca[3 + i], cb[3 + i]}, c001 = {ca[6 + i], cb[6 + i]},
+               c110 = {ca[9 + i], cb[9 + i]}, c101 = {ca[12 + i], cb[12 + i]}, c011 = {ca[15 + i], cb[15 + i]},
+               c111 = {ca[18 + i], cb[18 + i]};
+      d2[i] = c101 + pb * c111;
+      j0[i] = (c100 + pb * c110) + pc * d2[i];
+      a1[i] = c010 + pc * c011;
+      d1[i] = c110 + pc * c111;
+      a2[i] = c001 + pb * c011;
+    }
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      const float pa = Dk.x[a];
+      F2 j1[3], j2[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+      {
+        j1[i] = a1[i] + pa * d1[i];
+        j2[i] = a2[i] + pa * d2[i];
+      }
+      const F2 r0[3] = {j1[1] * j2[2] - j1[2] * j2[1], j1[2] * j2[0] - j1[0] * j2[2], j1[0] * j2[1] - j1[1] * j2[0]};
+      const F2 r1[3] = {j2[1] * j0[2] - j2[2] * j0[1], j2[2] * j0[0] - j2[0] * j0[2], j2[0] * j0[1] - j2[1] * j0[0]};
+      const F2 r2[3] = {j0[1] * j1[2] - j0[2] * j1[1], j0[2] * j1[0] - j0[0] * j1[2], j0[0] * j1[1] - j0[1] * j1[0]};
+      const F2 det = j0[0] * r0[0] + j0[1] * r0[1] + j0[2] * r0[2];
+      const F2 sc = (Dk.w[a] * wbc) * pk_rcp(pk_abs(det));
+      const F2 f0 = F0[a], f1 = F1[a], f2 = F2v[a];
+      F2 t[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        t[i] = sc * (f0 * r0[i] + f1 * r1[i] + f2 * r2[i]);
+      F0[a] = r0[0] * t[0] + r0[1] * t[1] + r0[2] * t[2];
+      F1[a] = r1[0] * t[0] + r1[1] * t[1] + r1[2] * t[2];
+      F2v[a] = r2[0] * t[0] + r2[1] * t[1] + r2[2] * t[2];
+    }
+  }
+  else
+  {
+    const float wbc = w_l[b] * w_l[c];
+    F2 Gc[6];
+#pragma unroll
+    for (int gi = 0; gi < 6; ++gi)
+      Gc[gi] = F2{gc_l[e0 * 7 + gi], gc_l[eb * 7 + gi]} * cf;
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+    {
+      const float w3 = w_l[a] * wbc;   // affine cell: G(q) = Gc w_q
+      const F2 w0 = F0[a] * w3, w1 = F1[a] * w3, w2 = F2v[a] * w3;
+      F0[a] = Gc[0] * w0 + Gc[1] * w1 + Gc[2] * w2;
+      F1[a] = Gc[1] * w0 + Gc[3] * w1 + Gc[4] * w2;
+      F2v[a] = Gc[2] * w0 + Gc[4] * w1 + Gc[5] * w2;
+    }
+  }
+  // transposed contractions, the same way round
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    sA[a * TS + p] = F1[a];
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    Tb[k] = sA[b * TS + k * N + c];
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+  {
+    F2 acc = F2(0.0f);
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+      acc += Dk.d[q * N + j] * Tb[q];
+    sA[b * TS + j * N + c] = acc;
+  }
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+  {
+    F2 acc = sA[a * TS + p];
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+      acc += Dk.d[q * N + a] * F0[q];
+    Y[a] = acc;
+  }
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    sA[a * TS + p] = F2v[a];
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int k = 0; k < N; ++k)
+    Uc[k] = sA[b * TS + c * N + k];
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int j = 0; j < N; ++j)
+  {
+    F2 acc = F2(0.0f);
+#pragma unroll
+    for (int q = 0; q < N; ++q)
+      acc += Dk.d[q * N + j] * Uc[q];
+    sA[b * TS + c * N + j] = acc;
+  }
+  FUS_WAVE_SYNC();
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+  {
+    Y[a] += sA[a * TS + p];
+    if (ATOMIC)
+    {
+      __hip_atomic_fetch_add(&y_l[li0[a]], Y[a][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (two)
+        __hip_atomic_fetch_add(&y_l[li1[a]], Y[a][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    else
+    {
+      y_l[li0[a]] += Y[a][0];
+      if (two)
+        y_l[li1[a]] += Y[a][1];
+    }
+  }
+  FUS_WAVE_SYNC();   // the tile is free for the next pair
+}
+
+// ---------------------------------------------------------------------------------------------
 // MFMA contraction path (degrees 6 and 7, per-cell geometry kernels; template parameter MF of k_block_op).
 // At N = 7, 8 one element fills a wave, and each of the index-1 / index-2 contractions of an element is an
 // (N x N) . (N x N^2) product -- the reference's contract<T, N, N, N, N, bool>
@@ -1370,7 +1606,7 @@ __device__ __forceinline__ void load_stage_args(const KArgs<T, N> __attribute__(
 // no geometry registers -- are compiled for FUS_TRI_WAVES(P) waves per SIMD with the lane's
 // derivative-table rows read from LDS where used.
 // TD = 2: the same block machinery for quadrilateral elements (Nd = N^2, GEOM_STREAM only).
-template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3, int MF = 0>
+template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3, int MF = 0, int PK = 0>
 __global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P >= 8) ? 1 : (P <= 4 && GEOM == GEOM_AFFINE)
                                                             ? 4
                                                             : ((GEOM == GEOM_TRILINEAR || (GEOM == GEOM_AFFINE && P <= 6)) ? FUS_TRI_WAVES(P) : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1)))
@@ -1384,6 +1620,11 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   constexpr int LPE = (N2 <= 64) ? 64 : 128;
   static_assert(N2 <= 128, "degrees up to 10");
   static_assert(LPE == 64 || (TD == 3 && GEOM != GEOM_STREAM && !MF), "degrees 8-10: hexahedra, per-cell geometry");
+  // packed fp32 (elem_compute_pk): a wave works on two elements at once
+  static_assert(!PK || (sizeof(T) == 4 && EPW == 1 && LPE == 64 && TD == 3 && OP == OP_STIFFNESS && ATOMIC && !MF
+                        && GEOM != GEOM_STREAM),
+                "packed path: fp32 stiffness, degrees 5-7, per-cell geometry, LDS-atomic accumulation");
+  constexpr int EPS = PK ? 2 : 1;   // elements per lane group and trip
 
   (void)kernel_args;
   // Kernel arguments are read from the kernarg segment where they are used, through a pointer that is
@@ -1400,7 +1641,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   // block loop in scalar registers)
 #define FUS_PHASE_LDS(q)                                                                           \
   const int lds_nloc = q->A.lds_nloc, lds_nelem = q->A.lds_nelem, nwaves = q->A.waves;             \
-  const int slots = (nwaves * 64 / LPE) * EPW;                                                     \
+  const int slots = (nwaves * 64 / LPE) * EPW * EPS;                                               \
   T* x_l = reinterpret_cast<T*>(smem_raw);                                                         \
   T* y_l = x_l + lds_nloc;                                                                         \
   T* x2_l = y_l + lds_nloc; /* second input (NF == 2 only) */                                      \
@@ -1431,10 +1672,10 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   const int s = lane / N2, p = lane - s * N2;                                                      \
   const int b = p / N, c = p - b * N;                                                              \
   const bool active = s < EPW;                                                                     \
-  const int myslot = wave * EPW + (active ? s : 0);                                                \
+  const int myslot = (wave * EPW + (active ? s : 0)) * EPS;                                        \
   /* exchange tiles follow x_l, y_l (, x2_l); one per element slot */                              \
   T* sA = reinterpret_cast<T*>(smem_raw) + (size_t)(NF == 2 ? 3 : 2) * q->A.lds_nloc                \
-          + (size_t)(wave * EPW + (active ? s : 0)) * (Nd + N);                                    \
+          + (size_t)myslot * (Nd + N);                                                             \
   T* sB = sA
 
   // A workgroup walks the blocks blk, blk + gridDim.x, ... of the launch's range (a launch with one
@@ -1695,7 +1936,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   {
     FUS_LANE_COORDS(q);
     (void)b, (void)c, (void)sA, (void)sB;
-    const int slots = (q->A.waves * 64 / LPE) * EPW;
+    const int slots = (q->A.waves * 64 / LPE) * EPW * EPS;
     const int nt0 = ATOMIC ? (Mm.sh.nelem + slots - 1) / slots : Mm.sh.nrounds;
     int e0 = -1;
     if (active && nt0 > 0)
@@ -1798,7 +2039,17 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
       elem_compute2d<T, N, OP, ATOMIC, NF>(in, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, ldm_l, cf_l,      \
                                            x2_l, cf2_l, p, b, c);                                  \
   } while (0)
-  if constexpr (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD))
+  if constexpr (PK)
+  {
+    for (int r = 0; r < ntrips; ++r)
+    {
+      const int i0 = r * slots + myslot;
+      const int e0 = (active && i0 < sh.nelem) ? i0 : -1, e1 = (active && i0 + 1 < sh.nelem) ? i0 + 1 : -1;
+      elem_compute_pk<N, ATOMIC, NF, GEOM>(e0, e1, Dk, x_l, y_l, reinterpret_cast<F2*>(sA), ldm_l, cf_l, x2_l, cf2_l,
+                                           gc_l, w_l, pt_l, p, b, c);
+    }
+  }
+  else if constexpr (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD))
   {
     for (int r = 0; r < ntrips; ++r)
     {

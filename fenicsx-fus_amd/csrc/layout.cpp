@@ -55,7 +55,7 @@ struct Rcb
 
 std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
                          const int32_t* dm, const double* centroids, int block_elems, int waves,
-                         const uint8_t* force_shared, int tdim)
+                         const uint8_t* force_shared, int tdim, int slot_factor)
 {
   if (P < 1 || P > 15)
     return "unsupported degree";
@@ -70,6 +70,7 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
   L.epw = std::max(1, 64 / (L.N * L.N));
   // degrees 8-10 on hexahedra: a tensor plane has more than 64 columns and two waves share an element
   L.slots = (tdim == 3 && L.N * L.N > 64) ? std::max(1, L.waves / 2) : L.waves * L.epw;
+  L.slots *= std::max(1, slot_factor);   // packed fp32 kernels: two elements per lane group and trip
   const int Nd = L.Nd;
   if (block_elems < 1)
     block_elems = 64;

@@ -78,7 +78,7 @@ struct Layout
 // Returns empty string or an error message.
 std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
                          const int32_t* tensor_dofmap, const double* centroids, int block_elems,
-                         int waves, const uint8_t* force_shared = nullptr, int tdim = 3);
+                         int waves, const uint8_t* force_shared = nullptr, int tdim = 3, int slot_factor = 1);
 
 // Internal consistency check used by fus_layout_check and the CPU tests.
 std::string verify_layout(const Layout& L, const int32_t* tensor_dofmap);

@@ -125,6 +125,9 @@ class SpectralOperatorData:
     def uses_mfma(self) -> bool:
         return bool(lib().fus_op_uses_mfma(self.h))
 
+    def uses_pack32(self) -> bool:
+        return bool(lib().fus_op_uses_pack32(self.h))
+
     def facet_diag(self, cells, local_facets, cellcoef):
         cells = np.ascontiguousarray(cells, dtype=np.int32)
         lf = np.ascontiguousarray(local_facets, dtype=np.int32)

@@ -79,6 +79,9 @@ int fus_synchronize(fus_ctx* ctx);
  * paths -- the index-1 / index-2 contractions of an element, the (N x N).(N x N^2) products of the
  * reference's contract<> (sum_factorisation.hpp:70-86), as 16x16x4 MFMA tiles on the matrix cores
  * instead of vector FMAs.  Auto = where it measured faster on MI355X (degree 7, fp64, trilinear geometry).
+ * "pack32" (-1 auto (default) | 0 | 1, before fus_op_create): fp32, degrees 5-7, per-cell geometry paths -- a
+ * wave works on two elements at once, every tile exchange and FMA packed as float2 (half the LDS and vector
+ * instructions per element of the scalar fp32 kernel, which is LDS bound).
  * "walk" (0 (default) | 1..8 | -1, any time): block-kernel workgroups per CU that walk several blocks each
  * with the next block's prologue loads in flight under the current block's epilogue; 0 = one workgroup
  * per block (measured faster everywhere so far, profiles/r02_experiments.md), -1 = as many as are resident.
@@ -170,6 +173,9 @@ int fus_op_geometry_mode(fus_op* op);
 /* 1 when the operator's block kernel runs its index-1 / index-2 contractions on the matrix cores
  * (MFMA 16x16x4; degrees 6 and 7 on the per-cell geometry paths, option "mfma"). */
 int fus_op_uses_mfma(fus_op* op);
+/* 1 when the fp32 stiffness kernel works on two elements per wave in packed float2 (degrees 5-7, per-cell
+ * geometry paths, LDS-atomic accumulation; option "pack32"). */
+int fus_op_uses_pack32(fus_op* op);
 /* Smallest cell size of the local mesh, the size of a cell being its largest vertex-to-vertex
  * distance (dolfinx::mesh::h, linear_planewave2d_1/main.cpp:60-64); dt = CFL hmin / (c P^2), :102. */
 int fus_op_hmin(fus_op* op, double* hmin);

@@ -156,3 +156,50 @@ def test_full_size_properties_p6_fp32():
     """64^3 p=6 fp32 (57 M dofs): configs[4]'s degree and arithmetic, one GPU's share of it in x."""
     n, _ = _full_size_properties("trilinear", 6, 64, 0.12, dtype=np.float32, tol_sym=2e-4, tol_one=2e-4)
     assert n == (64 * 6 + 1) ** 3
+
+
+@pytest.mark.parametrize("P", [5, 6, 7])
+@pytest.mark.parametrize("perturb,mode", [(0.2, "trilinear"), (0.0, "affine")])
+def test_packed_fp32_kernels(orc, P, perturb, mode):
+    """Option "pack32" (auto: where it measured faster): fp32 at degrees 5-7 on the per-cell geometry paths works on two elements per
+    wave in packed float2 (kernels.hpp, elem_compute_pk).  Operator action (odd number of cells: the last pair
+    is a lone element) and the Lossy RK4 loop (two operator inputs) against the float oracle and against the
+    scalar kernel."""
+    pr = Problem(orc, (3, 3, 3), P, hi=[0.012, 0.012, 0.012], perturb=perturb, dtype=np.float32)
+    rng = np.random.default_rng(P)
+    x = rng.standard_normal(pr.ndofs).astype(np.float32)
+    coef = rng.uniform(0.5, 2.0, pr.mesh.num_cells).astype(np.float32)
+    ref = pr.K(x, coef)
+    ys = {}
+    for pk in (1, 0):
+        c = fa.Context(0)
+        c.set_option("pack32", pk)
+        d = fa.SpectralOperatorData(pr.V, c)
+        assert d.geometry_mode() == mode and d.uses_pack32() == bool(pk)
+        ys[pk] = d.stiffness(x, coef, np.zeros(pr.ndofs, np.float32))
+        assert relmax(ys[pk], ref) < 5e-5
+        assert relmax(d.mass(x, coef, np.zeros(pr.ndofs, np.float32)), pr.M(x, coef)) < 1e-5
+        d.close()
+        c.close()
+    assert relmax(ys[1], ys[0]) < 2e-5
+    # Lossy model (NF = 2) through the packed kernel
+    nc = pr.mesh.num_cells
+    c0, rho0 = np.full(nc, 1500.0, np.float32), np.full(nc, 1000.0, np.float32)
+    delta = np.full(nc, fa.compute_diffusivity_of_sound(2 * np.pi * F0, 1500.0, 0.2), np.float32)
+    tags = tag_box_boundary(pr.mesh)
+    dt = 0.5 * (0.012 / 3) / (1500.0 * P**2)
+    nsteps = 10
+    m, src, absb, src2, lin, att = pr.lossy_model_vectors(c0, rho0, delta, tags)
+    u, v = np.zeros(pr.ndofs, np.float32), np.zeros(pr.ndofs, np.float32)
+    orc.lossy_rk4(3, pr.N, pr.dm, pr.G, pr.D, lin, att, m, src, absb, src2, F0, P0, S0, 0.0, nsteps * dt * (1 - 1e-6), dt, u, v,
+                  dtype=np.float32)
+    ctx = fa.Context(0)
+    ctx.set_option("pack32", 1)
+    model = fa.LossySpectralExplicit(pr.mesh, tags, P, c0, rho0, delta, F0, P0, S0, 4, dt, V=pr.V, ctx=ctx)
+    assert model.data.uses_pack32()
+    model.init()
+    model.rk4_steps(0.0, dt, nsteps)
+    un = model.u_sol().x.array
+    assert np.abs(u).max() > 0 and relmax(un, u) < 2e-4
+    model.close()
+    ctx.close()

@@ -1,9 +1,20 @@
 #!/bin/bash
-# usage: gpu_sweep.sh "args1" "args2" ...  -- one short bench per argument string
-for a in "$@"; do
-  timeout -k 10 300 python bench.py --no-cpu --steps 10 --warmup 2 $a > gpurun_out/bench_sweep.log 2> gpurun_out/bench_sweep.err
-  tail -1 gpurun_out/bench_sweep.log | python -c "
-import sys,json
-d=json.loads(sys.stdin.read())
-print('$a: geom %s value %.4e ms/step %.3f stiff_ms %.4f kfrac %.3f stepfrac %.3f lds %d blocks %d'%(d['config']['geometry'][:7], d['value'], d['ms_per_step'], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['step_roofline']['frac_of_8TBps'], d['config']['lds_bytes_per_block'], d['config']['blocks']))" || tail -5 gpurun_out/bench_sweep.log
-done
+# usage: gpu_sweep.sh <out.txt>   (through gpurun) -- one bench line per degree / precision / model at 64^3
+out=gpurun_out/$1
+: > $out
+run() {
+  timeout -k 10 400 python bench.py --no-cpu --traffic none --both-geometries 0 --repeats 3 $@ > gpurun_out/sweep_tmp.json 2>> gpurun_out/sweep.err \
+    && python - "$*" >> $out <<'PY'
+import json,sys
+d=json.load(open("gpurun_out/sweep_tmp.json"))
+r=d["roofline"]
+print("%-46s %.4g DOF-upd/s  %.4f ms/step  kernel %.4f ms  frac %.3f  mfma=%s pk=%s blocks=%d" % (sys.argv[1], d["value"], d["ms_per_step"], r["avg_launch_ms"], r["frac"], d["config"]["mfma_contractions"], d["config"]["packed_fp32"], d["config"]["blocks"]))
+PY
+}
+for P in 2 3 4 5 6 7; do run --P $P; run --P $P --geometry auto; done
+for P in 4 5 6 7; do run --P $P --dtype f32; done
+run --P 6 --dtype f32 --geometry auto
+run --P 8; run --P 9 --cells 32; run --P 10 --cells 32
+run --model lossy; run --model westervelt
+run --P 4 --geometry stream; run --P 7 --geometry stream
+cat $out

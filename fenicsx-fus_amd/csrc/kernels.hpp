@@ -715,14 +715,17 @@ __device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTa
         X[a] = x_l[li[a]];
     }
     // derivative along tensor index 0: registers only (spectral_op.hpp:194-196)
+    // (scheduling fences keep the table reads of one output at a time in registers: with everything
+    // unrolled and hoisted these kernels spill at the 256-register cap)
 #pragma unroll
     for (int q = 0; q < N; ++q)
     {
       T acc = T(0);
 #pragma unroll
       for (int i = 0; i < N; ++i)
-        acc += Dk.d[q * N + i] * X[i];
+        acc += D_l[q * N + i] * X[i];
       F0[q] = acc;
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (on)
     {
@@ -734,23 +737,24 @@ __device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTa
     // derivatives along tensor indices 1 and 2 (spectral_op.hpp:199-210)
 #pragma unroll
     for (int a = 0; a < N; ++a)
+      F1[a] = F2[a] = T(0);
+#pragma unroll 1
+    for (int j = 0; j < N; ++j)
     {
-      T f1 = T(0), f2 = T(0);
+      const T d1 = D_l[bb * N + j], d2 = D_l[cc * N + j];
 #pragma unroll
-      for (int j = 0; j < N; ++j)
+      for (int a = 0; a < N; ++a)
       {
-        f1 += D_l[bb * N + j] * sA[a * N2 + j * N + cc];
-        f2 += D_l[cc * N + j] * sA[a * N2 + bb * N + j];
+        F1[a] += d1 * sA[a * N2 + j * N + cc];
+        F2[a] += d2 * sA[a * N2 + bb * N + j];
       }
-      F1[a] = f1;
-      F2[a] = f2;
     }
     // stiffness::transform (spectral_op.hpp:113-130)
 #pragma unroll
     for (int a = 0; a < N; ++a)
     {
       if (GEOM == GEOM_TRILINEAR)
-        tri.transform(Dk.x[a], Dk.w[a] * wbc * cf, F0[a], F1[a], F2[a]);
+        tri.transform(pt_l[a], w_l[a] * wbc * cf, F0[a], F1[a], F2[a]);
       else
       {
         const T w3 = w_l[a] * w_l[bb] * w_l[cc];
@@ -779,11 +783,17 @@ __device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTa
       T acc = T(0);
 #pragma unroll
       for (int q = 0; q < N; ++q)
-        acc += Dk.d[q * N + a] * F0[q];
-#pragma unroll
-      for (int j = 0; j < N; ++j)
-        acc += D_l[j * N + bb] * sA[a * N2 + j * N + cc];
+        acc += D_l[q * N + a] * F0[q];
       Y[a] = acc;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll 1
+    for (int j = 0; j < N; ++j)
+    {
+      const T d1 = D_l[j * N + bb];
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        Y[a] += d1 * sA[a * N2 + j * N + cc];
     }
     __syncthreads();
     if (on)
@@ -793,14 +803,13 @@ __device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTa
         sA[a * N2 + pp] = F2[a];
     }
     __syncthreads();
-#pragma unroll
-    for (int a = 0; a < N; ++a)
+#pragma unroll 1
+    for (int j = 0; j < N; ++j)
     {
-      T acc = Y[a];
+      const T d2 = D_l[j * N + cc];
 #pragma unroll
-      for (int j = 0; j < N; ++j)
-        acc += D_l[j * N + cc] * sA[a * N2 + bb * N + j];
-      Y[a] = acc;
+      for (int a = 0; a < N; ++a)
+        Y[a] += d2 * sA[a * N2 + bb * N + j];
     }
     __syncthreads();   // the tile is free for the next element
   }
@@ -810,7 +819,7 @@ __device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTa
 #pragma unroll
     for (int a = 0; a < N; ++a)
       Y[a] = cf * x_l[li[a]]
-             * (GEOM == GEOM_TRILINEAR ? tri.detw(Dk.x[a], Dk.w[a] * wbc) : gc_l[er * 7 + 6] * (w_l[a] * w_l[bb] * w_l[cc]));
+             * (GEOM == GEOM_TRILINEAR ? tri.detw(pt_l[a], w_l[a] * wbc) : gc_l[er * 7 + 6] * (w_l[a] * w_l[bb] * w_l[cc]));
   }
   if (on)
   {

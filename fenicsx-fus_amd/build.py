@@ -14,7 +14,7 @@ DEPS = SRC + [os.path.join(HERE, "csrc", f) for f in ("kernels.hpp", "layout.hpp
 OUT = os.path.join(HERE, "fenicsxfus_amd", "libfusmi.so")
 
 
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-function",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-function", "-Wno-invalid-offsetof",
          "-munsafe-fp-atomics"]
 DEGREES = (2, 3, 4, 5, 6, 7, 8, 9, 10)
 

@@ -332,7 +332,7 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
   constexpr int N = P + 1;
   KArgs<T, N> K;
   for (int i = 0; i < N * N; ++i)
-    K.Dk.d[i] = (T)op->D[i];
+    K.Dk.d[i] = (T)op->D[i], K.Dk.dt[i] = (T)op->D[(i % N) * N + i / N];
   for (int i = 0; i < N; ++i)
     K.Dk.w[i] = (T)op->wts[i], K.Dk.x[i] = (T)op->nodes[i];
   // the attribute is per device: one bit per device and instantiation (set again harmlessly if two
@@ -1688,7 +1688,7 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   // trilinear map (GEOM_TRILINEAR) unless the streamed factors are asked for
   const bool trilinear_mesh = !affine_mesh && c->geometry != 1 && op->geom_order == 1 && op->tdim == 3;
   const bool two_per_cu = op->dtype == FUS_F64 && op->tdim == 3 && op->P >= 5 && !affine_mesh && !trilinear_mesh
-                          && !op->deterministic && c->block_elems <= 0;
+                          && c->block_elems <= 0;
   static const int be_two[8] = {0, 0, 0, 0, 0, 20, 12, 8};
   // per-cell geometry paths (affine, trilinear): about half the streamed size; at p >= 5 blocks of 8
   // elements, small enough for four / three / two blocks per CU at the register budgets of those

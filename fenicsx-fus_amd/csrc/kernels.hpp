@@ -98,9 +98,39 @@ __host__ __device__ constexpr bool stage_is_first(int st) { return st == 0 || st
 template <typename T, int N>
 struct DTab
 {
-  T d[N * N];
+  T d[N * N];    // derivative table, d[q * N + i] = phi_i'(x_q)
   T w[N], x[N];  // 1-D GLL weights and points (kernel argument -> scalar registers)
+  T dt[N * N];   // its transpose, dt[i * N + q] = d[q * N + i]
 };
+
+// One row of the derivative table (TR = 0: d[r][.]) or of its transpose (TR = 1: d[.][r]) as scalar operands.
+// fp64, N = 8: the table is 160 scalar registers and does not fit beside everything else; left to the
+// register allocator it lives in vector-register lanes and every FMA that uses an entry is preceded by a
+// v_readlane (+100 % vector instructions in the element trips at degree 7).  Here the row (one
+// s_load_dwordx16) is loaded from the kernarg segment where it is used, through a pointer made opaque per
+// use (scalar cache), and is dead after its N FMAs.  Only callable from k_block_op (whose only argument
+// starts with BlockArgs, then the DTab: KArgs).
+template <typename T, int N, int TR>
+__device__ __forceinline__ void dtab_row(const DTab<T, N>& Dk, int r, T (&out)[N])
+{
+  if constexpr (sizeof(T) == 8 && N == 8)   // (measured: -5.7 % kernel time at degree 7 trilinear; at degree 6 the
+  {                                         // 14-dword rows cost three scalar loads each and the kernels got 3-6 % slower)
+    typedef const T __attribute__((address_space(4))) * CP;
+    typedef const char __attribute__((address_space(4))) * CC;
+    // KArgs = { BlockArgs A; DTab Dk; ... } (checked in k_block_op); dt follows d, w, x inside the DTab
+    CP pr = (CP)((CC)__builtin_amdgcn_kernarg_segment_ptr() + sizeof(BlockArgs) + (TR ? sizeof(T) * (N * N + 2 * N) : 0)) + r * N;
+    asm volatile("" : "+s"(pr));
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      out[i] = pr[i];
+  }
+  else
+  {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+      out[i] = TR ? Dk.dt[r * N + i] : Dk.d[r * N + i];
+  }
+}
 
 // values per 16-byte (or 8-byte) geometry load
 template <typename T, int N>
@@ -144,9 +174,7 @@ enum
 
 // waves per SIMD the GEOM_TRILINEAR block kernel is compiled for: 4 (128 VGPRs) up to degree 5, 2 above
 // (degrees 6 / 7 need 161 / 184 VGPRs; capping 7 at 168 measured no gain)
-#ifndef FUS_TRI_WAVES
 #define FUS_TRI_WAVES(P) ((P) <= 5 ? 4 : 2)
-#endif
 // Geometry source of the block operator
 //   GEOM_STREAM: per-point factors G / detJw streamed from HBM (any trilinear mesh; the reference's
 //                data path, precompute.hpp:101-213)
@@ -411,21 +439,14 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
       for (int a = 0; a < N; ++a)
         X[a] = x_l[li[a]];
     }
-#ifndef FUS_REMAP_ON
-#define FUS_REMAP_ON 1
-#endif
     // REMAP: the index-1 and index-2 contractions also run in registers.  Lane (b, c) re-reads the tile
     // as lane (a' = b, c) with index 1 along its registers (then as (a' = b, b' = c) with index 2 along
     // them), contracts with the derivative table in scalar registers and writes the result back for
     // the (b, c) owner: 5 reads + 5 writes + 5 reads per direction instead of 25 reads + the lane's
     // derivative rows -- the element trips of the per-cell geometry kernels are bound by the LDS port.
-#ifndef FUS_REMAP_MAXN
-#define FUS_REMAP_MAXN 7  // degree 7 (N = 8) keeps the tile-read form: re-mapped it measured 5-14 % slower
-#endif
-#ifndef FUS_REMAP_STREAM
-#define FUS_REMAP_STREAM 0  // the streamed kernel sits on the bandwidth roofline: measured separately
-#endif
-    constexpr bool REMAP = FUS_REMAP_ON && (GEOM != GEOM_STREAM || FUS_REMAP_STREAM) && N <= FUS_REMAP_MAXN;
+    // Per-cell geometry kernels up to degree 6: degree 7 (N = 8) keeps the tile-read form (re-mapped it
+    // measured 5-14 % slower), and so does the streamed kernel (+1.5 % only: it sits on the bandwidth roof).
+    constexpr bool REMAP = GEOM != GEOM_STREAM && N <= 7;
     if constexpr (REMAP)
     {
       // plane stride of the tile: N^2, padded by one where the re-mapped accesses (lanes (b, c) at
@@ -434,10 +455,11 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
       for (int q = 0; q < N; ++q)
       {
-        T acc = T(0);
+        T acc = T(0), dr[N];
+        dtab_row<T, N, 0>(Dk, q, dr);
 #pragma unroll
         for (int i = 0; i < N; ++i)
-          acc += Dk.d[q * N + i] * X[i];
+          acc += dr[i] * X[i];
         F0[q] = acc;
       }
 #pragma unroll
@@ -455,10 +477,11 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
       for (int q = 0; q < N; ++q)
       {
-        T acc = T(0);
+        T acc = T(0), dr[N];
+        dtab_row<T, N, 0>(Dk, q, dr);
 #pragma unroll
         for (int k = 0; k < N; ++k)
-          acc += Dk.d[q * N + k] * Tb[k];
+          acc += dr[k] * Tb[k];
         sA[b * TS + q * N + c] = acc;  // d/dX1 at point (b, q, c)
       }
       FUS_WAVE_SYNC();
@@ -469,10 +492,11 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
       for (int q = 0; q < N; ++q)
       {
-        T acc = T(0);
+        T acc = T(0), dr[N];
+        dtab_row<T, N, 0>(Dk, q, dr);
 #pragma unroll
         for (int k = 0; k < N; ++k)
-          acc += Dk.d[q * N + k] * Uc[k];
+          acc += dr[k] * Uc[k];
         sA[b * TS + c * N + q] = acc;  // d/dX2 at point (b, c, q)
       }
       FUS_WAVE_SYNC();
@@ -513,20 +537,22 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
       for (int j = 0; j < N; ++j)
       {
-        T acc = T(0);
+        T acc = T(0), dc[N];
+        dtab_row<T, N, 1>(Dk, j, dc);
 #pragma unroll
         for (int q = 0; q < N; ++q)
-          acc += Dk.d[q * N + j] * Tb[q];
+          acc += dc[q] * Tb[q];
         sA[b * TS + j * N + c] = acc;
       }
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
       {
-        T acc = sA[a * TS + p];
+        T acc = sA[a * TS + p], dc[N];
+        dtab_row<T, N, 1>(Dk, a, dc);
 #pragma unroll
         for (int q = 0; q < N; ++q)
-          acc += Dk.d[q * N + a] * F0[q];
+          acc += dc[q] * F0[q];
         Y[a] = acc;
       }
       FUS_WAVE_SYNC();
@@ -541,10 +567,11 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
       for (int j = 0; j < N; ++j)
       {
-        T acc = T(0);
+        T acc = T(0), dc[N];
+        dtab_row<T, N, 1>(Dk, j, dc);
 #pragma unroll
         for (int q = 0; q < N; ++q)
-          acc += Dk.d[q * N + j] * Uc[q];
+          acc += dc[q] * Uc[q];
         sA[b * TS + c * N + j] = acc;
       }
       FUS_WAVE_SYNC();
@@ -558,10 +585,11 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
     for (int q = 0; q < N; ++q)
     {
-      T acc = T(0);
+      T acc = T(0), dr[N];
+      dtab_row<T, N, 0>(Dk, q, dr);
 #pragma unroll
       for (int i = 0; i < N; ++i)
-        acc += Dk.d[q * N + i] * X[i];
+        acc += dr[i] * X[i];
       F0[q] = acc;
     }
 #pragma unroll
@@ -618,10 +646,11 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
     for (int a = 0; a < N; ++a)
     {
-      T acc = T(0);
+      T acc = T(0), dc[N];
+      dtab_row<T, N, 1>(Dk, a, dc);
 #pragma unroll
       for (int q = 0; q < N; ++q)
-        acc += Dk.d[q * N + a] * F0[q];
+        acc += dc[q] * F0[q];
 #pragma unroll
       for (int j = 0; j < N; ++j)
         acc += (DLDS ? D_l[j * N + b] : Dcb[j]) * sA[a * N2 + j * N + c];
@@ -1221,10 +1250,11 @@ __device__ __forceinline__ void elem_compute_mfma(const ElemIn<T, N, OP_STIFFNES
 #pragma unroll
   for (int q = 0; q < N; ++q)
   {
-    T acc = T(0);
+    T acc = T(0), dr[N];
+    dtab_row<T, N, 0>(Dk, q, dr);
 #pragma unroll
     for (int i = 0; i < N; ++i)
-      acc += Dk.d[q * N + i] * X[i];
+      acc += dr[i] * X[i];
     F0[q] = acc;
   }
   if (on)
@@ -1295,10 +1325,11 @@ __device__ __forceinline__ void elem_compute_mfma(const ElemIn<T, N, OP_STIFFNES
 #pragma unroll
     for (int a = 0; a < N; ++a)
     {
-      T acc = sA[mfma_tix<N>(a, pb_i, pc_i)];
+      T acc = sA[mfma_tix<N>(a, pb_i, pc_i)], dc[N];
+      dtab_row<T, N, 1>(Dk, a, dc);
 #pragma unroll
       for (int q = 0; q < N; ++q)
-        acc += Dk.d[q * N + a] * F0[q];
+        acc += dc[q] * F0[q];
       Y[a] = acc;
     }
   }
@@ -1370,10 +1401,11 @@ __device__ __forceinline__ bool elem_stiff_fwd(const ElemIn<T, N, OP_STIFFNESS, 
 #pragma unroll
   for (int q = 0; q < N; ++q)
   {
-    T acc = T(0);
+    T acc = T(0), dr[N];
+    dtab_row<T, N, 0>(Dk, q, dr);
 #pragma unroll
     for (int i = 0; i < N; ++i)
-      acc += Dk.d[q * N + i] * X[i];
+      acc += dr[i] * X[i];
     F0[q] = acc;
   }
 #pragma unroll
@@ -1418,7 +1450,7 @@ __device__ __forceinline__ bool elem_stiff_fwd(const ElemIn<T, N, OP_STIFFNESS, 
   return true;
 }
 
-template <typename T, int N, int DL = 0>
+template <typename T, int N, int DL = 0, int ATOMIC = 1>
 __device__ __forceinline__ void elem_stiff_bwd(const DTab<T, N>& Dk, const T (&Dcb_)[N], const T (&Dcc_)[N],
                                                const T* __restrict__ D_l,
                                                T* __restrict__ y_l, T* __restrict__ sA, int p, int b,
@@ -1442,10 +1474,11 @@ __device__ __forceinline__ void elem_stiff_bwd(const DTab<T, N>& Dk, const T (&D
 #pragma unroll
   for (int a = 0; a < N; ++a)
   {
-    T acc = T(0);
+    T acc = T(0), dc[N];
+    dtab_row<T, N, 1>(Dk, a, dc);
 #pragma unroll
     for (int q = 0; q < N; ++q)
-      acc += Dk.d[q * N + a] * F0[q];
+      acc += dc[q] * F0[q];
 #pragma unroll
     for (int j = 0; j < N; ++j)
       acc += Dcb[j] * sA[a * N2 + j * N + c];
@@ -1467,21 +1500,19 @@ __device__ __forceinline__ void elem_stiff_bwd(const DTab<T, N>& Dk, const T (&D
   }
 #pragma unroll
   for (int a = 0; a < N; ++a)
-    __hip_atomic_fetch_add(&y_l[li[a]], Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  {
+    if (ATOMIC)
+      __hip_atomic_fetch_add(&y_l[li[a]], Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+      y_l[li[a]] += Y[a];   // conflict-free rounds: elements of one round share no dof
+  }
 }
 
-// Single geometry register set (see elem_stiff_fwd): fp64, degrees 5 and 6, streamed geometry,
-// LDS-atomic accumulation.  With two sets those kernels need 290-330 registers, i.e. one wave per
+// Single geometry register set (see elem_stiff_fwd): degrees 5-7, streamed geometry (fp64 and fp32, LDS-atomic
+// and conflict-free-round accumulation).  With two sets those kernels need 290-380 registers, i.e. one wave per
 // SIMD and one block per CU; with one set they fit 256: two waves per SIMD, two blocks per CU.
-#ifdef FUS_NO_PF1  // experiment switch
-#define FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) 0
-#else
 #define FUS_PF1(T, P, OP, ATOMIC, GEOM, TD)                                                         \
-  ((sizeof(T) == 8 && (P) >= 5 && (P) <= FUS_PF1_MAXP && (OP) == OP_STIFFNESS && (ATOMIC) && (GEOM) == GEOM_STREAM && (TD) == 3) ? 1 : 0)
-#ifndef FUS_PF1_MAXP
-#define FUS_PF1_MAXP 7
-#endif
-#endif
+  (((P) >= 5 && (P) <= 7 && (OP) == OP_STIFFNESS && (GEOM) == GEOM_STREAM && (TD) == 3) ? 1 : 0)
 
 // Fused RK4 stage update of ONE dof s whose right-hand side sum `acc` (= b) is complete.
 // kv = b * minv  (Linear.hpp:212-221), ku = vn (f0, :171-174).
@@ -1622,6 +1653,10 @@ __global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P >= 8) ? 1 : (P <= 4 &
 k_block_op(const KArgs<T, P + 1> kernel_args)
 {
   static_assert(TD == 3 || GEOM == GEOM_STREAM, "quadrilaterals use the streamed geometry");
+  typedef KArgs<T, P + 1> KArgsT;
+  typedef DTab<T, P + 1> DTabT;
+  static_assert(offsetof(KArgsT, Dk) == sizeof(BlockArgs) && offsetof(DTabT, dt) == sizeof(T) * ((P + 1) * (P + 1) + 2 * (P + 1)),
+                "dtab_row reads the table at these kernarg offsets");
   constexpr int N = P + 1, N2 = N * N, Nd = (TD == 3) ? N * N * N : N * N;
   constexpr int EPW = (64 / N2) > 0 ? (64 / N2) : 1;
   // lanes that work on one element slot group: a wave, or two waves where a tensor plane has more than
@@ -1635,7 +1670,6 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
                 "packed path: fp32 stiffness, degrees 5-7, per-cell geometry, LDS-atomic accumulation");
   constexpr int EPS = PK ? 2 : 1;   // elements per lane group and trip
 
-  (void)kernel_args;
   // Kernel arguments are read from the kernarg segment where they are used, through a pointer that is
   // made opaque again at the start of every phase (FUS_KARGS): a workgroup that walks several blocks
   // would otherwise keep all ~150 scalar registers' worth of arguments live around the block loop and
@@ -2023,13 +2057,10 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
 
   // ---- trips, two per iteration: while one register set is consumed the other is in flight ----
   FUS_KARGS(qt);
-  DTab<T, N> Dk;   // derivative table, 1-D weights and points -> scalar registers for the trips
-#pragma unroll
-  for (int i = 0; i < N * N; ++i)
-    Dk.d[i] = qt->Dk.d[i];
-#pragma unroll
-  for (int i = 0; i < N; ++i)
-    Dk.w[i] = qt->Dk.w[i], Dk.x[i] = qt->Dk.x[i];
+  // derivative table, 1-D weights and points: read straight from the kernel argument (plain kernarg loads,
+  // which the register allocator re-issues where it would otherwise spill scalar registers -- at N = 8 the
+  // table alone is 160 of them)
+  const DTab<T, N>& Dk = kernel_args.Dk;
   const T* __restrict__ geo = qt->geo;
 #define FUS_ELEM_COMPUTE(in)                                                                       \
   do                                                                                               \
@@ -2069,7 +2100,9 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
                                                     c, li, F0, F1, F2);
       elem_fetch<T, N, OP, GEOM, TD>(inA, elem_of(r + 1), geo, elem_off, p);
       if (act)
-        elem_stiff_bwd<T, N, DL>(Dk, Dcb, Dcc, D_l, y_l, sA, p, b, c, li, F0, F1, F2);
+        elem_stiff_bwd<T, N, DL, ATOMIC>(Dk, Dcb, Dcc, D_l, y_l, sA, p, b, c, li, F0, F1, F2);
+      if (!ATOMIC && nwaves > 1)
+        __syncthreads();   // rounds are ordered
     }
   }
   else

@@ -333,6 +333,7 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
   KArgs<T, N> K;
   for (int i = 0; i < N * N; ++i)
     K.Dk.d[i] = (T)op->D[i], K.Dk.dt[i] = (T)op->D[(i % N) * N + i / N];
+
   for (int i = 0; i < N; ++i)
     K.Dk.w[i] = (T)op->wts[i], K.Dk.x[i] = (T)op->nodes[i];
   // the attribute is per device: one bit per device and instantiation (set again harmlessly if two

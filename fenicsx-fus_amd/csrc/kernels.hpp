@@ -100,7 +100,7 @@ struct DTab
 {
   T d[N * N];    // derivative table, d[q * N + i] = phi_i'(x_q)
   T w[N], x[N];  // 1-D GLL weights and points (kernel argument -> scalar registers)
-  T dt[N * N];   // its transpose, dt[i * N + q] = d[q * N + i]
+  T dt[N * N];   // its transpose, dt[i * N + q] = d[q * N + i] (read by dtab_row at N = 8)
 };
 
 // One row of the derivative table (TR = 0: d[r][.]) or of its transpose (TR = 1: d[.][r]) as scalar operands.
@@ -108,13 +108,15 @@ struct DTab
 // register allocator it lives in vector-register lanes and every FMA that uses an entry is preceded by a
 // v_readlane (+100 % vector instructions in the element trips at degree 7).  Here the row (one
 // s_load_dwordx16) is loaded from the kernarg segment where it is used, through a pointer made opaque per
-// use (scalar cache), and is dead after its N FMAs.  Only callable from k_block_op (whose only argument
-// starts with BlockArgs, then the DTab: KArgs).
+// use (scalar cache), and is dead after its N FMAs: -5.7 % kernel time at degree 7 trilinear.  Lower degrees
+// keep the whole table in scalar registers (k_block_op copies it there before the trips): per-row loads
+// measured 3-6 % slower at degree 6 (also with rows padded to one load each) and degree 5.
+// Only callable from k_block_op (whose only argument starts with BlockArgs, then the DTab: KArgs).
 template <typename T, int N, int TR>
 __device__ __forceinline__ void dtab_row(const DTab<T, N>& Dk, int r, T (&out)[N])
 {
-  if constexpr (sizeof(T) == 8 && N == 8)   // (measured: -5.7 % kernel time at degree 7 trilinear; at degree 6 the
-  {                                         // 14-dword rows cost three scalar loads each and the kernels got 3-6 % slower)
+  if constexpr (sizeof(T) == 8 && N == 8)
+  {
     typedef const T __attribute__((address_space(4))) * CP;
     typedef const char __attribute__((address_space(4))) * CC;
     // KArgs = { BlockArgs A; DTab Dk; ... } (checked in k_block_op); dt follows d, w, x inside the DTab
@@ -128,7 +130,7 @@ __device__ __forceinline__ void dtab_row(const DTab<T, N>& Dk, int r, T (&out)[N
   {
 #pragma unroll
     for (int i = 0; i < N; ++i)
-      out[i] = TR ? Dk.dt[r * N + i] : Dk.d[r * N + i];
+      out[i] = TR ? Dk.d[i * N + r] : Dk.d[r * N + i];
   }
 }
 
@@ -1652,6 +1654,7 @@ __global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P >= 8) ? 1 : (P <= 4 &
                                                             : ((GEOM == GEOM_TRILINEAR || (GEOM == GEOM_AFFINE && P <= 6)) ? FUS_TRI_WAVES(P) : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1)))
 k_block_op(const KArgs<T, P + 1> kernel_args)
 {
+  (void)kernel_args;
   static_assert(TD == 3 || GEOM == GEOM_STREAM, "quadrilaterals use the streamed geometry");
   typedef KArgs<T, P + 1> KArgsT;
   typedef DTab<T, P + 1> DTabT;
@@ -2057,10 +2060,18 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
 
   // ---- trips, two per iteration: while one register set is consumed the other is in flight ----
   FUS_KARGS(qt);
-  // derivative table, 1-D weights and points: read straight from the kernel argument (plain kernarg loads,
-  // which the register allocator re-issues where it would otherwise spill scalar registers -- at N = 8 the
-  // table alone is 160 of them)
-  const DTab<T, N>& Dk = kernel_args.Dk;
+  // derivative table (N = 8 in fp64: read row by row where used, dtab_row), 1-D weights and points -> scalar
+  // registers for the trips
+  DTab<T, N> Dk;
+  if constexpr (!(sizeof(T) == 8 && N == 8))
+  {
+#pragma unroll
+    for (int i = 0; i < N * N; ++i)
+      Dk.d[i] = qt->Dk.d[i];
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i)
+    Dk.w[i] = qt->Dk.w[i], Dk.x[i] = qt->Dk.x[i];
   const T* __restrict__ geo = qt->geo;
 #define FUS_ELEM_COMPUTE(in)                                                                       \
   do                                                                                               \

@@ -175,6 +175,9 @@ struct fus_ctx
   // -1 auto (the measured choice per degree, scalar type and geometry), 0 never, 1 wherever a variant exists
   int mfma = -1;
   int pack32 = -1;  // fp32, degrees 5-7, per-cell geometry: two elements per wave in packed float2 (-1 auto, 0, 1)
+  // shared-dof stage kernel reads the partial sums as planes at the dof's own index (1, default) or through the
+  // shared-dof CSR (0; also taken when a dof has more than FUS_MAX_PLANES sharing blocks): same sums, same order
+  int planes = 1;
   int walk = 0;   // block-kernel workgroups per CU that walk several blocks each (0: one workgroup per block --
                   // the measured best everywhere so far; -1: as many as are resident), see launch_block_op_v
 };
@@ -247,6 +250,8 @@ struct fus_model
   int32_t* d_bidx = nullptr;
   int32_t* d_blk_bnd_off = nullptr;
   int32_t *d_sh_ptr32 = nullptr, *d_sh_pairs32 = nullptr;  // shared CSR incl. boundary pseudo pairs
+  uint64_t* d_bnd_mask = nullptr;                           // rank-local shared dofs: boundary dof bits ...
+  int32_t* d_bnd_base = nullptr;                            // ... and boundary dofs ahead of each 64-dof word
   void *d_bsrc = nullptr, *d_babs = nullptr;
   std::vector<void*> allocs;
   bool initialised = false;
@@ -669,7 +674,16 @@ static int op_setup_device(fus_op* op)
   FUSCHK(upload(pool, &op->d_cell_perm, L.cell_perm, st));
   FUSCHK(upload(pool, &op->d_dof_perm, L.dof_perm, st));
   FUSCHK(upload(pool, &op->d_sh_ptr, L.sh_ptr, st));
-  FUSCHK(upload(pool, &op->d_sh_pairs, L.sh_pairs, st));
+  {
+    // the CSR the kernels read holds where each pair's partial sum is stored (Layout::pair_pos), not its pair id
+    std::vector<int64_t> pos(L.sh_pairs.size());
+    for (size_t k = 0; k < pos.size(); ++k)
+      pos[k] = L.pair_pos[L.sh_pairs[k]];
+    FUSCHK(upload(pool, &op->d_sh_pairs, pos, st));
+  }
+  int32_t* d_sh_ppos;
+  FUSCHK(upload(pool, &d_sh_ppos, L.pair_pos, st));
+  op->A.sh_ppos = d_sh_ppos;
   op->A.blk_shape = d_blk_shape, op->A.shapes = d_shapes, op->A.blk_elem_off = d_elem_off;
   op->A.blk_int_off = d_int_off, op->A.blk_sh_off = d_sh_off, op->A.sh_gidx = d_sh_gidx;
   op->A.rounds = d_rounds, op->A.ldm = d_ldm, op->A.nblocks = L.nblocks;
@@ -739,7 +753,7 @@ static int op_setup_device(fus_op* op)
   else
     FUSCHK((ensure_stream_geometry<T, P>(op)));
 
-  FUSCHK(dalloc_bytes(pool, &op->d_partial, (size_t)(L.npairs + L.n_shared) * sizeof(T), true, st));
+  FUSCHK(dalloc_bytes(pool, &op->d_partial, (size_t)(L.n_partial + L.n_shared) * sizeof(T), true, st));
   FUSCHK(dalloc_bytes(pool, &op->d_tmp_x, (size_t)L.n_internal * sizeof(T), true, st));
   FUSCHK(dalloc_bytes(pool, &op->d_tmp_b, (size_t)L.n_internal * sizeof(T), true, st));
   FUSCHK(dalloc_bytes(pool, &op->d_tmp_c, (size_t)op->ndofs * sizeof(T), true, st));
@@ -1050,26 +1064,44 @@ static int model_setup_finish(fus_model* m)
                          - bidx.begin());
     off[L.nblocks] = (int32_t)m->nb_int;
     FUSCHK(upload(m->allocs, &m->d_blk_bnd_off, off, st));
-    // shared CSR of this model: the op's pairs + one trailing pseudo pair (slot npairs + k) for the
-    // k-th shared boundary dof, so the boundary term is the last addend like Linear.hpp:204-205
-    if (L.npairs + L.n_shared > 2000000000ll)
+    // shared CSR of this model: where the op's pairs keep their partial sums + one trailing pseudo pair (slot
+    // n_partial + k) for the k-th shared boundary dof, so the boundary term is the last addend like
+    // Linear.hpp:204-205
+    if (L.n_partial + L.n_shared > 2000000000ll)
       return fail(FUS_ERR_LIMIT, "partial slab exceeds int32 indexing");
     std::vector<int32_t> extra(L.n_shared, -1);
     for (int64_t k = m->nb_int; k < m->nb; ++k)
-      extra[bidx[k] - L.n_int_pad] = (int32_t)(L.npairs + (k - m->nb_int));
+      extra[bidx[k] - L.n_int_pad] = (int32_t)(L.n_partial + (k - m->nb_int));
     std::vector<int32_t> ptr(L.n_shared + 1), prs;
     prs.reserve(L.npairs + (m->nb - m->nb_int));
     for (int64_t sidx = 0; sidx < L.n_shared; ++sidx)
     {
       ptr[sidx] = (int32_t)prs.size();
       for (int64_t k = L.sh_ptr[sidx]; k < L.sh_ptr[sidx + 1]; ++k)
-        prs.push_back((int32_t)L.sh_pairs[k]);
+        prs.push_back(L.pair_pos[L.sh_pairs[k]]);
       if (extra[sidx] >= 0)
         prs.push_back(extra[sidx]);
     }
     ptr[L.n_shared] = (int32_t)prs.size();
     FUSCHK(upload(m->allocs, &m->d_sh_ptr32, ptr, st));
     FUSCHK(upload(m->allocs, &m->d_sh_pairs32, prs, st));
+    // the same for the plane form of the rank-local shared dofs (k_shared_stage_planes): one bit per dof and the
+    // number of boundary dofs ahead of each 64-dof word (bidx ascends, so the k-th set bit is the k-th term)
+    m->d_bnd_mask = nullptr, m->d_bnd_base = nullptr;
+    if (m->nb > m->nb_int && L.n_shared_local > 0)
+    {
+      const int64_t nw = (L.n_shared_local + 63) / 64;
+      std::vector<uint64_t> mask(nw, 0);
+      std::vector<int32_t> base(nw, 0);
+      for (int64_t sidx = 0; sidx < L.n_shared_local; ++sidx)
+        if (extra[sidx] >= 0)
+          mask[sidx >> 6] |= 1ull << (sidx & 63);
+      // boundary dofs of the interface range come after every local one in bidx, so the local ranks start at 0
+      for (int64_t w = 1; w < nw; ++w)
+        base[w] = base[w - 1] + __builtin_popcountll(mask[w - 1]);
+      FUSCHK(upload(m->allocs, &m->d_bnd_mask, mask, st));
+      FUSCHK(upload(m->allocs, &m->d_bnd_base, base, st));
+    }
   }
   T *d_bsrc, *d_babs;
   FUSCHK(upload(m->allocs, &m->d_bidx, bidx, st));
@@ -1249,7 +1281,7 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
                        static_cast<const T*>(m->d_babs) + m->nb_int, S.gval,
                        m->d_bsrc2 ? static_cast<const T*>(m->d_bsrc2) + m->nb_int : nullptr, S.dgval,
                        static_cast<const T*>(i == 0 ? m->v0 : m->vn),
-                       static_cast<T*>(op->d_partial) + op->L.npairs);
+                       static_cast<T*>(op->d_partial) + op->L.n_partial);
   }
   // interface dofs (held by other ranks too): this rank's partials are summed into b and into the
   // send buffer by one kernel; the event hands the buffer to the exchange
@@ -1297,11 +1329,11 @@ static int stage_end(fus_model* m, int i, double t, double dt)
   BndNext<T> B{};
   const int64_t nbs = m->nb - m->nb_int;
   m->bnd_valid = false;
-  if (m->rk_order == 4 && nbs > 0 && op->L.npairs + nbs < INT32_MAX)
+  if (m->rk_order == 4 && nbs > 0 && op->L.n_partial + nbs < INT32_MAX)
   {
     const StageScalars scn = i < 3 ? stage_scalars<T>(m, i + 1, t, dt)
                                    : stage_scalars<T>(m, 0, (double)((T)t + (T)dt), dt);
-    B.enabled = 1, B.npairs = (int32_t)op->L.npairs;
+    B.enabled = 1, B.npairs = (int32_t)op->L.n_partial;
     B.srcw = static_cast<const T*>(m->d_bsrc) + m->nb_int;
     B.absw = static_cast<const T*>(m->d_babs) + m->nb_int;
     B.src2w = m->d_bsrc2 ? static_cast<const T*>(m->d_bsrc2) + m->nb_int : nullptr;
@@ -1312,7 +1344,31 @@ static int stage_end(fus_model* m, int i, double t, double dt)
   }
   const LeanRK<T> R{(T)sc.b0dt, (T)sc.r0, (T)sc.r1};
   const int kind = stage_kind(m, i);
-  if (nloc > 0)
+  if (nloc > 0 && c->planes && (int)op->L.plane_cnt.size() <= FUS_MAX_PLANES)
+  {
+    ProfScope ps(c, "stage");
+    const dim3 grid(nblk(nloc)), blk(256);
+    PartialPlanes PL{};
+    PL.bnd0 = (int32_t)op->L.n_partial;
+    for (size_t j = 0; j < op->L.plane_cnt.size(); ++j)
+      PL.cnt[j] = (int32_t)op->L.plane_cnt[j], PL.off[j] = (int32_t)op->L.plane_off[j];
+#define FUS_PLANES_CASE(K)                                                                         \
+  case K:                                                                                          \
+    hipLaunchKernelGGL((k_shared_stage_planes<T, K>), grid, blk, 0, st, nloc, PL, m->d_bnd_mask, m->d_bnd_base,      \
+                       partial, minv + off, vn + off, un + off, u0 + off, v0 + off, u_ + off, v_ + off, adt, bdt,    \
+                       m0p, mn1p, B, R);                                                           \
+    break;
+    switch (kind)
+    {
+      FUS_PLANES_CASE(0) FUS_PLANES_CASE(3) FUS_PLANES_CASE(4) FUS_PLANES_CASE(5) FUS_PLANES_CASE(6)
+    default:
+      hipLaunchKernelGGL((k_shared_stage_planes<T, 1>), grid, blk, 0, st, nloc, PL, m->d_bnd_mask, m->d_bnd_base,
+                         partial, minv + off, vn + off, un + off, u0 + off, v0 + off, u_ + off, v_ + off, adt, bdt,
+                         m0p, mn1p, B, R);
+    }
+#undef FUS_PLANES_CASE
+  }
+  else if (nloc > 0)
   {
     ProfScope ps(c, "stage");
     const dim3 grid(nblk(nloc)), blk(256);
@@ -1853,6 +1909,8 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
       return fail(FUS_ERR_ARG, "pack32 must be -1 (auto), 0 or 1");
     c->pack32 = (int)value;
   }
+  else if (!strcmp(key, "planes"))
+    c->planes = value != 0;
   else if (!strcmp(key, "walk"))
   {
     if (value < -1 || value > 8)

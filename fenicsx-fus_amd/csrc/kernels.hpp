@@ -38,6 +38,7 @@ struct BlockArgs
   const int32_t* blk_int_off;
   const int64_t* blk_sh_off;
   const int32_t* sh_gidx;
+  const int32_t* sh_ppos;  // where each (block, shared slot) pair's partial sum goes (Layout::pair_pos)
   const int16_t* rounds;
   const uint16_t* ldm;
   int32_t nblocks;
@@ -2168,6 +2169,14 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   load_stage_args<T, N>(qe, S);
   T* __restrict__ bvec = qe->bvec;
   T* __restrict__ partial = qe->partial;
+  // where this block's partial sums go: requested now, used after the interior dofs (the stores would otherwise
+  // wait for a memory round trip of their own at the very end of the block)
+  const int32_t* __restrict__ pp = qe->A.sh_ppos + sh_off;
+  const int nsh = sh.nloc - sh.nint;
+  int ppv[US];
+#pragma unroll
+  for (int u = 0; u < US; ++u)
+    ppv[u] = (tid + u * nthr < nsh) ? pp[tid + u * nthr] : -1;
 
   // ---- epilogue: each dof written once ----
   const int nvec = sh.nint >> 1;
@@ -2318,8 +2327,12 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
       }
     }
   }
-  for (int l = sh.nint + tid; l < sh.nloc; l += nthr)
-    partial[sh_off + (l - sh.nint)] = y_l[l];
+#pragma unroll
+  for (int u = 0; u < US; ++u)
+    if (ppv[u] >= 0)
+      partial[ppv[u]] = y_l[sh.nint + tid + u * nthr];
+  for (int k = tid + US * nthr; k < nsh; k += nthr)
+    partial[pp[k]] = y_l[sh.nint + k];
   }
   FUS_TRACE_END(blk);
   if (!has_next)
@@ -2387,7 +2400,55 @@ __device__ __forceinline__ void boundary_next(const BndNext<T>& B, int32_t last_
 
 
 
-// Shared dofs of one rank: fixed-order sum of the partials fused with the RK4 stage update of
+// The partial sums of the rank-local shared dofs as planes (Layout::pair_pos): plane j holds, at the dof's own
+// index, the contribution of the dof's j-th sharing block; cnt[j] dofs (a prefix of the range) have one.
+constexpr int FUS_MAX_PLANES = 16;
+struct PartialPlanes
+{
+  int32_t bnd0;                  // slot of the first boundary term (after every pair's partial sum)
+  int32_t cnt[FUS_MAX_PLANES];   // 0 for the planes that do not exist
+  int32_t off[FUS_MAX_PLANES];
+};
+
+// Shared dofs of one rank, partial sums in planes: sum over the planes in ascending order (= ascending block
+// order, the order of the CSR form below: same bits), then the boundary term of a shared boundary dof
+// (bnd_mask: one bit per dof, bnd_base: boundary dofs ahead of the 64-dof word; the k-th boundary dof's term is
+// in slot PL.bnd0 + k), fused with the RK4 stage update.  No index list is read: every access is at s.
+template <typename T, int STAGE>
+__global__ void __launch_bounds__(256)
+k_shared_stage_planes(int64_t n, const PartialPlanes PL, const uint64_t* __restrict__ bnd_mask,
+                      const int32_t* __restrict__ bnd_base, const T* __restrict__ partial,
+                      const T* __restrict__ minv, T* __restrict__ vn, T* __restrict__ un, T* __restrict__ u0,
+                      T* __restrict__ v0, T* __restrict__ u_, T* __restrict__ v_, T adt, T bdt,
+                      const T* __restrict__ m0, const T* __restrict__ mn1, const BndNext<T> B, const LeanRK<T> R)
+{
+  const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= n)
+    return;
+  T acc = T(0);
+#pragma unroll
+  for (int j = 0; j < FUS_MAX_PLANES; ++j)
+  {
+    if (s < PL.cnt[j])
+      acc += partial[(int64_t)PL.off[j] + s];
+  }
+  int32_t pair = -1;
+  if (bnd_mask)
+  {
+    const uint64_t w = bnd_mask[s >> 6];
+    const int bit = (int)(s & 63);
+    if ((w >> bit) & 1ull)
+    {
+      pair = PL.bnd0 + bnd_base[s >> 6] + __builtin_popcountll(w & ((1ull << bit) - 1ull));
+      acc += partial[pair];
+    }
+  }
+  const T vnext = stage_update_dof<T, STAGE>(s, acc, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0, mn1, R);
+  boundary_next<T>(B, pair, vnext);
+}
+
+// Shared dofs of one rank, CSR form (more than FUS_MAX_PLANES sharers of one dof, or option "planes" = 0):
+// fixed-order sum of the partials fused with the RK4 stage update of
 // stage_update_dof; vectors are passed offset to the shared range.
 template <typename T, int STAGE>
 __global__ void __launch_bounds__(256)

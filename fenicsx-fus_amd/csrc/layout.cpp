@@ -8,6 +8,7 @@
 #include <cstring>
 #include <map>
 #include <numeric>
+#include <unordered_map>
 
 namespace fus
 {
@@ -108,6 +109,8 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
   // ---- 2. how many blocks touch each dof ----
   std::vector<int32_t> last_blk(ndofs, -1);
   std::vector<uint8_t> nblk(ndofs, 0);
+  std::vector<uint64_t> sharers(ndofs, 0);  // signature of the set of blocks touching the dof (its "group": a face,
+                                            // an edge or a corner between blocks)
   for (int32_t b = 0; b < L.nblocks; ++b)
     for (int64_t k = leaves[b].first; k < leaves[b].second; ++k)
     {
@@ -121,6 +124,7 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
           last_blk[d[i]] = b;
           if (nblk[d[i]] < 255)
             ++nblk[d[i]];
+          sharers[d[i]] = (sharers[d[i]] ^ (uint64_t)(b + 1)) * 0x9E3779B97F4A7C15ull;
         }
       }
     }
@@ -145,6 +149,8 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
   int64_t int_cursor = 0;
   std::vector<uint64_t> rmask;
   std::vector<uint16_t> key;
+  std::vector<int32_t> shl;                          // the block's shared dofs
+  std::unordered_map<uint64_t, int32_t> grp_rank;    // group signature -> order of first appearance in the block
 
   for (int32_t b = 0; b < L.nblocks; ++b)
   {
@@ -209,25 +215,39 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
         ++er;
       }
 
-    // final local numbering: interior dofs first, then shared, each by first appearance
+    // final local numbering: interior dofs first (by first appearance), then shared, group after group (groups
+    // and the dofs of a group by first appearance): the dofs a block shares with one set of other blocks are
+    // then a run of its slots AND, numbered below in this order, a run of the shared range -- the gather of
+    // their values and the store of their partial sums touch whole cache lines.  Blocks of one shape still get
+    // one local dofmap (the order depends on the block's own traversal only).
     int32_t nint = 0, nsh = 0;
-    for (int pass = 0; pass < 2; ++pass)
+    shl.clear();
+    for (int32_t e = 0; e < nelem; ++e)
     {
-      for (int32_t e = 0; e < nelem; ++e)
+      const int32_t* d = dm + (int64_t)erel_cell[e] * Nd;
+      for (int i = 0; i < Nd; ++i)
       {
-        const int32_t* d = dm + (int64_t)erel_cell[e] * Nd;
-        for (int i = 0; i < Nd; ++i)
-        {
-          const int32_t g = d[i];
-          const bool shared = nblk[g] > 1;
-          if (pass == 0)
-          {
-            if (!shared && loc_blk[g] == b)
-              loc_blk[g] = -2 - b, loc_of[g] = nint++;   // mark assigned
-          }
-          else if (shared && loc_blk[g] == b)
-            loc_blk[g] = -2 - b, loc_of[g] = nint + nsh++;
-        }
+        const int32_t g = d[i];
+        if (loc_blk[g] != b)
+          continue;
+        loc_blk[g] = -2 - b;   // mark assigned
+        if (nblk[g] > 1)
+          shl.push_back(g);
+        else
+          loc_of[g] = nint++;
+      }
+    }
+    {
+      grp_rank.clear();
+      for (int32_t g : shl)
+        grp_rank.emplace(sharers[g], (int32_t)grp_rank.size());
+      std::stable_sort(shl.begin(), shl.end(),
+                       [&](int32_t a, int32_t c) { return grp_rank[sharers[a]] < grp_rank[sharers[c]]; });
+      for (int32_t g : shl)
+      {
+        loc_of[g] = nint + nsh++;
+        if (sh_id[g] < 0)
+          sh_id[g] = (int32_t)L.n_shared++;
       }
     }
     const int32_t nloc = nint + nsh;
@@ -260,11 +280,7 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
         if (l < nint)
           L.dof_perm[g] = (int32_t)(int_cursor + l);
         else
-        {
-          if (sh_id[g] < 0)
-            sh_id[g] = (int32_t)L.n_shared++;
           pair_shid[L.blk_sh_off[b] + (l - nint)] = sh_id[g];
-        }
       }
     }
     int_cursor += nint;
@@ -292,38 +308,44 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
     if (nblk[g] == 0)
       sh_id[g] = (int32_t)L.n_shared++;
 
-  // shared dofs held by other ranks too (interface dofs) go last in the shared range, so the
-  // rank-local shared dofs and the interface dofs are two contiguous index ranges
+  // Order of the shared range.  Rank-local shared dofs first, by DESCENDING number of sharing blocks (first
+  // appearance within a class): the dofs with more than k sharers are then a prefix of the range for every k,
+  // which is what lets the partial sums be stored as planes (below).  Shared dofs held by other ranks too
+  // (interface dofs) go last, so that the rank-local shared dofs and the interface dofs are two contiguous
+  // index ranges; the interface range starts on a 128-byte boundary (the slots in between stay empty).
   L.n_shared_local = L.n_shared;
   L.n_if_start_pad = L.n_shared;
-  if (force_shared)
   {
     std::vector<int64_t> owner(L.n_shared, -1);
     for (int64_t g = 0; g < ndofs; ++g)
       if (sh_id[g] >= 0)
         owner[sh_id[g]] = g;
-    int64_t nlocal = 0;
+    std::vector<int32_t> mult(L.n_shared, 0);
+    for (auto v : pair_shid)
+      ++mult[v];
+    std::vector<int32_t> local;
+    local.reserve(L.n_shared);
     for (int64_t k = 0; k < L.n_shared; ++k)
-      if (!force_shared[owner[k]])
-        ++nlocal;
-    const int64_t nif = L.n_shared - nlocal;
-    if (nif > 0)
-    {
-      // the interface range starts on a 128-byte boundary (the slots in between stay empty)
-      const int64_t start = (nlocal + 15) & ~(int64_t)15;
-      std::vector<int32_t> remap(L.n_shared, -1);
-      int64_t cl = 0, ci = start;
-      for (int64_t k = 0; k < L.n_shared; ++k)
-        remap[k] = (int32_t)(force_shared[owner[k]] ? ci++ : cl++);
-      for (int64_t g = 0; g < ndofs; ++g)
-        if (sh_id[g] >= 0)
-          sh_id[g] = remap[sh_id[g]];
-      for (auto& v : pair_shid)
-        v = remap[v];
-      L.n_shared_local = nlocal;
-      L.n_if_start_pad = start;
-      L.n_shared = start + nif;
-    }
+      if (!(force_shared && force_shared[owner[k]]))
+        local.push_back((int32_t)k);
+    std::stable_sort(local.begin(), local.end(), [&](int32_t a, int32_t b) { return mult[a] > mult[b]; });
+    const int64_t nlocal = (int64_t)local.size(), nif = L.n_shared - nlocal;
+    const int64_t start = nif > 0 ? ((nlocal + 15) & ~(int64_t)15) : nlocal;
+    std::vector<int32_t> remap(L.n_shared, -1);
+    for (int64_t k = 0; k < nlocal; ++k)
+      remap[local[k]] = (int32_t)k;
+    int64_t ci = start;
+    for (int64_t k = 0; k < L.n_shared; ++k)
+      if (remap[k] < 0)
+        remap[k] = (int32_t)ci++;
+    for (int64_t g = 0; g < ndofs; ++g)
+      if (sh_id[g] >= 0)
+        sh_id[g] = remap[sh_id[g]];
+    for (auto& v : pair_shid)
+      v = remap[v];
+    L.n_shared_local = nlocal;
+    L.n_if_start_pad = start;
+    L.n_shared = start + nif;
   }
 
   L.n_int_pad = (int_cursor + 15) & ~(int64_t)15;
@@ -349,6 +371,42 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
     for (int64_t k = 0; k < L.npairs; ++k)
       L.sh_pairs[cur[pair_shid[k]]++] = k;
   }
+  // Where a pair's partial sum lives (pair_pos).  Rank-local shared dof s, its j-th sharing block (ascending
+  // block order): plane_off[j] + s -- plane j holds one value for every dof with more than j sharers, a prefix of
+  // the local range, so the reduction reads plane after plane at the dof's own index, coalesced and without an
+  // index list.  Pairs of interface dofs follow the planes in CSR order.
+  L.plane_cnt.clear(), L.plane_off.clear();
+  int64_t cursor = 0;
+  for (int j = 0;; ++j)
+  {
+    int64_t cnt = 0;  // dofs with more than j sharers: a prefix (descending order), found by bisection
+    {
+      int64_t lo = 0, hi = L.n_shared_local;
+      while (lo < hi)
+      {
+        const int64_t mid = (lo + hi) / 2;
+        if (L.sh_ptr[mid + 1] - L.sh_ptr[mid] > j)
+          lo = mid + 1;
+        else
+          hi = mid;
+      }
+      cnt = lo;
+    }
+    if (cnt == 0)
+      break;
+    L.plane_cnt.push_back(cnt), L.plane_off.push_back(cursor);
+    cursor = (cursor + cnt + 15) & ~(int64_t)15;
+  }
+  L.pair_pos.assign(L.npairs, -1);
+  for (int64_t sidx = 0; sidx < L.n_shared_local; ++sidx)
+    for (int64_t k = L.sh_ptr[sidx]; k < L.sh_ptr[sidx + 1]; ++k)
+      L.pair_pos[L.sh_pairs[k]] = (int32_t)(L.plane_off[k - L.sh_ptr[sidx]] + sidx);
+  const int64_t if_first = L.sh_ptr[std::min(L.n_if_start_pad, L.n_shared)];
+  for (int64_t k = if_first; k < L.npairs; ++k)
+    L.pair_pos[L.sh_pairs[k]] = (int32_t)(cursor + (k - if_first));
+  L.n_partial = cursor + (L.npairs - if_first);
+  if (L.n_partial + L.n_shared > 2000000000ll)
+    return "partial slab exceeds int32 indexing";
   return "";
 }
 
@@ -426,6 +484,14 @@ std::string verify_layout(const Layout& L, const int32_t* dm)
   }
   if (pairs_seen != L.npairs)
     return "pair count mismatch";
+  {
+    std::vector<char> taken(L.n_partial, 0);
+    for (int64_t k = 0; k < L.npairs; ++k)
+    {
+      if (L.pair_pos[k] < 0 || L.pair_pos[k] >= L.n_partial || taken[L.pair_pos[k]]++)
+        return "two pairs share a partial position";
+    }
+  }
   for (int64_t s = 0; s < L.n_shared; ++s)
     for (int64_t k = L.sh_ptr[s]; k < L.sh_ptr[s + 1]; ++k)
     {
@@ -433,6 +499,11 @@ std::string verify_layout(const Layout& L, const int32_t* dm)
         return "shared CSR inconsistent";
       if (k > L.sh_ptr[s] && L.sh_pairs[k] <= L.sh_pairs[k - 1])
         return "shared CSR not in ascending block order";
+      const int64_t pos = L.pair_pos[L.sh_pairs[k]], j = k - L.sh_ptr[s];
+      if (pos < 0 || pos >= L.n_partial)
+        return "partial position out of range";
+      if (s < L.n_shared_local && (j >= (int64_t)L.plane_cnt.size() || s >= L.plane_cnt[j] || pos != L.plane_off[j] + s))
+        return "partial position is not (plane of the sharer's rank, dof index)";
     }
   return "";
 }

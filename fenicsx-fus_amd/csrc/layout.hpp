@@ -57,6 +57,12 @@ struct Layout
   int64_t n_internal = 0;             // padded internal vector length (multiple of 16)
   std::vector<int64_t> sh_ptr;        // [n_shared+1] CSR: shared dof -> pair indices
   std::vector<int64_t> sh_pairs;      // [npairs] ascending block order
+  // position of each pair's partial sum in the slab of n_partial values: plane_off[j] + s for the j-th sharer
+  // of rank-local shared dof s (plane j covers the plane_cnt[j] dofs with more than j sharers: a prefix of the
+  // local range, which is ordered by descending sharer count); pairs of interface dofs follow the planes
+  std::vector<int32_t> pair_pos;      // [npairs]
+  std::vector<int64_t> plane_cnt, plane_off;
+  int64_t n_partial = 0;
   int32_t max_nloc = 0, max_rounds = 0, max_nelem = 0;
 
   // nfields: operator inputs staged per block (1: Linear; 2: Lossy, K(c1) u + K(c2) v in one pass)

@@ -85,6 +85,9 @@ int fus_synchronize(fus_ctx* ctx);
  * "walk" (0 (default) | 1..8 | -1, any time): block-kernel workgroups per CU that walk several blocks each
  * with the next block's prologue loads in flight under the current block's epilogue; 0 = one workgroup
  * per block (measured faster everywhere so far, profiles/r02_experiments.md), -1 = as many as are resident.
+ * "planes" (1 (default) | 0, any time): the shared-dof stage kernel reads the block partial sums of a dof as
+ * planes at the dof's own index (no index list; every access coalesced) or through the shared-dof CSR; the
+ * sums and their order are the same (CSR is also taken when a dof has more than 16 sharing blocks).
  * Unknown keys -> FUS_ERR_ARG. */
 int fus_set_option(fus_ctx* ctx, const char* key, int64_t value);
 

@@ -688,3 +688,43 @@ def test_walking_workgroups(orc, geometry, perturb, walk):
     assert np.abs(u).max() > 0 and relmax(un.x.array, u) < TOL_RK and relmax(vn.x.array, v) < TOL_RK
     model.close()
     cx.close()
+
+
+@pytest.mark.parametrize("block_elems,P", [(1, 2), (4, 3), (None, 4)])
+@pytest.mark.parametrize("kind", ["linear", "lossy"])
+def test_shared_stage_planes_and_csr_agree_bitwise(orc, block_elems, P, kind):
+    """The shared-dof stage kernel in its two forms (option "planes"): partial sums read as planes at the dof's
+    own index, or through the shared-dof CSR.  Same addends in the same order (ascending block, boundary term
+    last): the deterministic kernels must give identical bits, and both must match the oracle.  One-element
+    blocks: every dof off a cell interior is shared, vertices by 8 blocks (8 planes)."""
+    n, L = (6, 5, 4), 0.012
+    pr, c, rho, tags = _linear_setup(orc, None, n, P, [L * 1.5, L * 1.25, L], perturb=0.15, hetero=True)
+    dt = 0.5 * (L / 4) / (c.max() * P**2)
+    nsteps = 5
+    tf = nsteps * dt * (1 - 1e-9)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    if kind == "linear":
+        m, src, absb, coeff = pr.linear_model_vectors(c, rho, tags)
+        orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, 0.5e6, 6e4, 1500.0, 0.0, tf, dt, u, v)
+    else:
+        delta = np.where(c > 2000.0, fa.compute_diffusivity_of_sound(2 * np.pi * 0.5e6, 2800.0, 46.0),
+                         fa.compute_diffusivity_of_sound(2 * np.pi * 0.5e6, 1500.0, 0.2))
+        m, src, absb, src2, lin, att = pr.lossy_model_vectors(c, rho, delta, tags)
+        orc.lossy_rk4(3, pr.N, pr.dm, pr.G, pr.D, lin, att, m, src, absb, src2, 0.5e6, 6e4, 1500.0, 0.0, tf, dt, u, v)
+    assert np.abs(u).max() > 0
+    outs = {}
+    for planes in (1, 0):
+        kw = {} if block_elems is None else {"block_elems": block_elems}
+        cx = fa.Context(0, deterministic=1, **kw)
+        cx.set_option("planes", planes)
+        if kind == "linear":
+            model = fa.LinearSpectralExplicit(pr.mesh, tags, P, c, rho, 0.5e6, 6e4, 1500.0, 4, dt, V=pr.V, ctx=cx)
+        else:
+            model = fa.LossySpectralExplicit(pr.mesh, tags, P, c, rho, delta, 0.5e6, 6e4, 1500.0, 4, dt, V=pr.V, ctx=cx)
+        model.init()
+        un, vn, _ = model.rk(0.0, tf)
+        outs[planes] = (un.x.array.copy(), vn.x.array.copy())
+        assert relmax(outs[planes][0], u) < TOL_RK and relmax(outs[planes][1], v) < TOL_RK
+        model.close()
+        cx.close()
+    assert np.array_equal(outs[1][0], outs[0][0]) and np.array_equal(outs[1][1], outs[0][1])

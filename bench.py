@@ -589,6 +589,18 @@ def main():
             "kernel_ms_per_step": prof["breakdown_ms_per_step"],
             "finite_nonzero_solution": finite,
         }
+        # the step's second kernel: stage update of the rank-local shared dofs = their block partial sums (8.. planes at
+        # the dof's own index) + the stage's model vectors; RK4 stage kinds 4, 5, 6, 3 stream 5, 7, 10, 6 vectors
+        st_ms = prof["breakdown_ms_per_step"].get("stage", 0.0)
+        if st_ms > 0 and args.model == "linear" and world == 1 and not args.halo_loopback:
+            nsh, npairs = info["shared_dofs"], info["pairs"]
+            st_bytes = (npairs + 7.0 * nsh) * s            # average stage of the four
+            out["second_kernel"] = {"kernel": "k_shared_stage_planes (rank-local shared dofs: partial sums + fused RK4 stage)",
+                                    "shared_dofs": int(nsh), "partial_sums": int(npairs), "avg_launch_ms": st_ms / 4,
+                                    "algorithmic_bytes_per_launch": st_bytes,
+                                    "achieved_GBps": st_bytes / (st_ms / 4 * 1e-3) / 1e9,
+                                    "frac_of_8TBps": st_bytes / (st_ms / 4 * 1e-3) / 8e12,
+                                    "share_of_step": st_ms / (1e3 * elapsed / args.steps)}
         if overlap_ab:
             out["exchange_overlap"] = {"what": "ms per step with the exchange hidden behind the shared-dof stage kernel only "
                                                "(off) or also behind the non-interface blocks (on), timed during warm-up",

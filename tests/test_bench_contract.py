@@ -47,6 +47,8 @@ def test_bench_json_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["achieved"] > 0
     assert r["traffic"] is None and r["frac_real"] is None   # no committed PMC passes for this small configuration
+    k2 = d["second_kernel"]                                   # the shared-dof stage kernel beside the dominant one
+    assert k2["shared_dofs"] > 0 and k2["partial_sums"] >= 2 * k2["shared_dofs"] and 0 < k2["share_of_step"] < 1
     rp = d["repeats"]
     assert rp["n"] == 3 and len(rp["ms_per_step"]) == 3 and rp["min"] <= d["ms_per_step"] <= rp["max"]
     c = d["cpu_baseline"]

@@ -69,6 +69,11 @@ def build(force: bool = False, verbose: bool = False, dev: bool = False, name: s
         _link(_compile_units(os.path.join(objroot, name), (degree,),
                              ["-DFUS_DEV_BUILD", f"-DFUS_DEV_DEGREE={degree}", *defines], verbose), out, verbose)
         return out
+    if name != "dev":   # full-library variant for A/B runs of compiler flags: abl/libfusmi_<name>.so
+        out = os.path.join(HERE, "..", "abl", f"libfusmi_{name}.so")
+        os.makedirs(os.path.dirname(out), exist_ok=True)
+        _link(_compile_units(os.path.join(objroot, name), DEGREES, list(defines), verbose), out, verbose)
+        return out
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     _link(_compile_units(os.path.join(objroot, "full"), DEGREES, [], verbose), OUT, verbose)
@@ -79,4 +84,4 @@ if __name__ == "__main__":
     nm = sys.argv[sys.argv.index("--name") + 1] if "--name" in sys.argv else "dev"
     deg = int(sys.argv[sys.argv.index("--degree") + 1]) if "--degree" in sys.argv else 4
     print(build(force="--force" in sys.argv, verbose="-q" not in sys.argv, dev="--dev" in sys.argv, name=nm,
-                defines=[a for a in sys.argv if a.startswith("-D")], degree=deg))
+                defines=[a for a in sys.argv if a.startswith("-D")] + (sys.argv[sys.argv.index("--") + 1:] if "--" in sys.argv else []), degree=deg))

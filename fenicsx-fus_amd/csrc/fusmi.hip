@@ -178,6 +178,9 @@ struct fus_ctx
   // shared-dof stage kernel reads the partial sums as planes at the dof's own index (1, default) or through the
   // shared-dof CSR (0; also taken when a dof has more than FUS_MAX_PLANES sharing blocks): same sums, same order
   int planes = 1;
+  // affine meshes whose cells have mutually orthogonal edges (boxes): the stiffness action in its diagonal-metric
+  // form (three 1-D stiffness contractions, kernels.hpp elem_compute) -- 1 (default) where the mesh allows, 0 never
+  int diag_metric = 1;
   int walk = 0;   // block-kernel workgroups per CU that walk several blocks each (0: one workgroup per block --
                   // the measured best everywhere so far; -1: as many as are resident), see launch_block_op_v
 };
@@ -215,6 +218,8 @@ struct fus_op
   bool affine = false;     // GEOM_AFFINE path in use (d_Gc), streamed G/detJ built only on demand
   bool trilinear = false;  // GEOM_TRILINEAR path in use (d_Gc holds 21 map coefficients per cell)
   bool mfma = false;       // MFMA contraction variants of the block kernel in use (degrees 6, 7)
+  bool ortho_mesh = false; // every cell a parallelepiped with mutually orthogonal edges (found in op_build)
+  bool diag = false;       // GEOM_AFFINE in its diagonal-metric form (ortho_mesh, degrees <= 7, option "diag_metric")
   bool pk = false;         // packed fp32 variants in use (degrees 5-7: two elements per wave, layout slots doubled)
   void* d_Gc = nullptr;
   void *d_xg = nullptr, *d_pts = nullptr, *d_wts = nullptr;
@@ -352,6 +357,20 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
     attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
   }
   K.A = op->A;
+  K.A.diag = 0;
+  if (GEOM == GEOM_AFFINE && OP == OP_STIFFNESS && TD == 3 && !MF && !PK && P <= 7 && op->diag)
+  {
+    // the 1-D stiffness matrix K1 = D^T diag(w) D takes the derivative table's place (symmetric: d = dt)
+    K.A.diag = 1;
+    for (int q = 0; q < N; ++q)
+      for (int i = 0; i < N; ++i)
+      {
+        double acc = 0;
+        for (int m = 0; m < N; ++m)
+          acc += op->D[m * N + q] * op->wts[m] * op->D[m * N + i];
+        K.Dk.d[q * N + i] = K.Dk.dt[q * N + i] = (T)acc;
+      }
+  }
   K.A.blk_begin = blk_begin;
   K.A.blk_count = blk_count;
   K.Dg = static_cast<const T*>(op->d_Dg), K.geo = geo, K.coef = coef, K.x = x, K.bvec = bvec;
@@ -741,6 +760,7 @@ static int op_setup_device(fus_op* op)
   // A/B measurements on MI355X (profiles/r02_mfma.md)
   op->mfma = (P == 6 || P == 7) && (op->affine || op->trilinear) && !op->deterministic
              && (c->mfma == 1 || (c->mfma < 0 && mfma_default(P, sizeof(T) == 8, op->affine)));
+  op->diag = op->affine && op->ortho_mesh && c->diag_metric && P <= 7 && !op->mfma && !op->pk;
   if (op->affine)
     op->lds_bytes = L.lds_bytes(sizeof(T), op->nfields, 7);
   else if (op->trilinear)
@@ -1676,6 +1696,7 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   // will the per-cell (affine) geometry path be taken?  (same test as k_geometry_affine, on the host
   // copy: every vertex of every cell on the parallelepiped spanned by vertices 0, 1, 2, 4)
   bool affine_mesh = c->geometry == 0 && op->geom_order == 1 && op->tdim == 3;
+  bool ortho_mesh = affine_mesh;
   for (int64_t cidx = 0; cidx < op->ncells && affine_mesh; ++cidx)
   {
     double cd[8][3], h2 = 0, e2 = 0;
@@ -1698,7 +1719,23 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
     const double tol = op->dtype == FUS_F64 ? 1e-12 : 1e-6;
     if (std::sqrt(e2 / h2) > 0.5 * tol)
       affine_mesh = false;
+    // mutually orthogonal edges: J^T J, and with it G = |det J| (J^T J)^-1, is diagonal
+    double ed[3][3];
+    for (int i = 0; i < 3; ++i)
+      ed[0][i] = cd[1][i] - cd[0][i], ed[1][i] = cd[2][i] - cd[0][i], ed[2][i] = cd[4][i] - cd[0][i];
+    for (int u = 0; u < 3; ++u)
+      for (int v = u + 1; v < 3; ++v)
+      {
+        double dot = 0, nu = 0, nv2 = 0;
+        for (int i = 0; i < 3; ++i)
+          dot += ed[u][i] * ed[v][i], nu += ed[u][i] * ed[u][i], nv2 += ed[v][i] * ed[v][i];
+        if (std::fabs(dot) > (op->dtype == FUS_F64 ? 1e-14 : 2e-7) * std::sqrt(nu * nv2))
+          ortho_mesh = false;
+      }
   }
+  op->ortho_mesh = affine_mesh && ortho_mesh;
+  // diagonal-metric form of the affine kernel: scalar kernels of the degrees <= 7 (no packed / matrix-core variant)
+  const bool diag_mesh = op->ortho_mesh && c->diag_metric && op->P <= 7 && !(c->mfma == 1) && !(c->pack32 == 1);
   // auto block size: about 2-3 thousand local dofs per block when G is streamed (128 / 64 / 32
   // elements at P = 2 / 3 / >= 4; larger P shrink further to fit LDS), half of that on the affine
   // path (profiles/r01_block_sweep.txt)
@@ -1759,7 +1796,7 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   // on affine cells (+2 %); slower at degree 6 trilinear (-12 %: 137 registers, three waves per SIMD) and degree 7
   op->pk = op->dtype == FUS_F32 && op->tdim == 3 && op->P >= 5 && op->P <= 7 && (affine_mesh || trilinear_mesh)
            && !c->deterministic && c->mfma != 1
-           && (c->pack32 == 1 || (c->pack32 < 0 && (op->P == 5 || (op->P == 6 && affine_mesh))));
+           && (c->pack32 == 1 || (c->pack32 < 0 && !diag_mesh && (op->P == 5 || (op->P == 6 && affine_mesh))));
   // fp32 halves the LDS per block: the trilinear kernel takes 16 elements at p >= 5 (+9-12 %), the
   // affine one at p = 5 only (+5 %; 16 is 2-9 % slower at p = 6, 7)
   const bool hi32 = op->dtype == FUS_F32 && op->tdim == 3 && op->P >= 5;
@@ -1911,6 +1948,8 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
   }
   else if (!strcmp(key, "planes"))
     c->planes = value != 0;
+  else if (!strcmp(key, "diag_metric"))
+    c->diag_metric = value != 0;
   else if (!strcmp(key, "walk"))
   {
     if (value < -1 || value > 8)
@@ -2227,6 +2266,7 @@ static void layout_info(const Layout& L, size_t ts, int64_t out[8])
 int fus_op_is_affine(fus_op* op) { return (op && op->affine) ? 1 : 0; }
 int fus_op_geometry_mode(fus_op* op) { return !op ? 0 : (op->affine ? 1 : (op->trilinear ? 2 : 0)); }
 int fus_op_uses_mfma(fus_op* op) { return (op && op->mfma) ? 1 : 0; }
+int fus_op_uses_diag_metric(fus_op* op) { return (op && op->diag) ? 1 : 0; }
 int fus_op_uses_pack32(fus_op* op) { return (op && op->pk && !op->mfma) ? 1 : 0; }
 
 int fus_op_info(fus_op* op, int64_t out[8])

@@ -47,6 +47,7 @@ struct BlockArgs
   int32_t lds_nloc;  // LDS array length (>= max nloc, even)
   int32_t lds_nelem; // LDS per-element table length (>= max elements per block, multiple of 8)
   int32_t waves;
+  int32_t diag;      // affine cells with orthogonal edges: G = diag(g0, g1, g2) w_q (elem_compute, diagonal-metric form)
 };
 
 // Arguments of the fused RK4 stage epilogue of k_block_op (STAGE >= 0): the model vectors in
@@ -406,7 +407,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
                                              const T* __restrict__ cf_l, const T* __restrict__ x2_l,
                                              const T* __restrict__ cf2_l, const T* __restrict__ gc_l,
                                              const T (&w3)[N], const T* __restrict__ D_l, T wbc, T pb,
-                                             T pc, int p, int b, int c)
+                                             T pc, int p, int b, int c, bool diag = false)
 {
   constexpr int N2 = N * N, Nd = N * N * N;
   constexpr int VW = GLoad<T, N>::VW;
@@ -450,7 +451,68 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
     // Per-cell geometry kernels up to degree 6: degree 7 (N = 8) keeps the tile-read form (re-mapped it
     // measured 5-14 % slower), and so does the streamed kernel (+1.5 % only: it sits on the bandwidth roof).
     constexpr bool REMAP = GEOM != GEOM_STREAM && N <= 7;
-    if constexpr (REMAP)
+    // Diagonal metric (affine cells with mutually orthogonal edges -- boxes in any orientation): G(q) = diag(g) w_q, so
+    //   K x = sum_d g_d (M x .. x K1 x .. x M) x,   K1 = D^T diag(w) D  (the 1-D stiffness matrix, in Dk.d here),
+    // three contractions instead of six and no pointwise transform.  Index 0 in registers; indices 1 and 2 as in
+    // the re-mapped form below: one store of X, the two re-mapped reads, and one store + read per result.
+    if (GEOM == GEOM_AFFINE && diag)
+    {
+      constexpr int TS = (N == 8 || N == 4) ? N2 + 1 : N2;
+      const T g0 = gc_l[in.er * 7 + 0] * cf * wbc, g1 = gc_l[in.er * 7 + 3] * cf * wbc,
+              g2 = gc_l[in.er * 7 + 5] * cf * wbc;   // w_b w_c of the lane's column, whichever two indices it spans
+#pragma unroll
+      for (int q = 0; q < N; ++q)
+      {
+        T acc = T(0), kr[N];
+        dtab_row<T, N, 0>(Dk, q, kr);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          acc += kr[i] * X[i];
+        Y[q] = g0 * acc;
+      }
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        sA[a * TS + p] = X[a];
+      FUS_WAVE_SYNC();
+      T Tb[N], Uc[N];
+#pragma unroll
+      for (int k = 0; k < N; ++k)
+      {
+        Tb[k] = sA[b * TS + k * N + c];
+        Uc[k] = sA[b * TS + c * N + k];
+      }
+      FUS_WAVE_SYNC();
+#pragma unroll
+      for (int q = 0; q < N; ++q)
+      {
+        T acc = T(0), kr[N];
+        dtab_row<T, N, 0>(Dk, q, kr);
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          acc += kr[k] * Tb[k];
+        sA[b * TS + q * N + c] = g1 * acc;   // index-1 term at point (b, q, c)
+      }
+      FUS_WAVE_SYNC();
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        Y[a] += sA[a * TS + p];
+      FUS_WAVE_SYNC();
+#pragma unroll
+      for (int q = 0; q < N; ++q)
+      {
+        T acc = T(0), kr[N];
+        dtab_row<T, N, 0>(Dk, q, kr);
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+          acc += kr[k] * Uc[k];
+        sA[b * TS + c * N + q] = g2 * acc;   // index-2 term at point (b, c, q)
+      }
+      FUS_WAVE_SYNC();
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        Y[a] += sA[a * TS + p];
+    }
+    else if constexpr (REMAP)
     {
       // plane stride of the tile: N^2, padded by one where the re-mapped accesses (lanes (b, c) at
       // b * TS + ...) would otherwise fall on the same LDS banks for every b (N = 8: 8-way, N = 4: 2-way)
@@ -2055,7 +2117,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
 #pragma unroll
     for (int a = 0; a < N; ++a)
       w3[a] = (GEOM == GEOM_AFFINE) ? w_l[a] * w_l[b] * w_l[c] : T(0);  // w_q = w_a w_b w_c of this lane's points
-    wbc = (GEOM == GEOM_TRILINEAR) ? w_l[b] * w_l[c] : T(0);
+    wbc = (GEOM == GEOM_TRILINEAR || GEOM == GEOM_AFFINE) ? w_l[b] * w_l[c] : T(0);
     pb = (GEOM == GEOM_TRILINEAR) ? pt_l[b] : T(0), pc = (GEOM == GEOM_TRILINEAR) ? pt_l[c] : T(0);
   }
 
@@ -2074,6 +2136,8 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   for (int i = 0; i < N; ++i)
     Dk.w[i] = qt->Dk.w[i], Dk.x[i] = qt->Dk.x[i];
   const T* __restrict__ geo = qt->geo;
+  const bool diag_metric = (GEOM == GEOM_AFFINE && OP == OP_STIFFNESS && TD == 3 && !MF && !PK && LPE == 64) && qt->A.diag != 0;
+  (void)diag_metric;
 #define FUS_ELEM_COMPUTE(in)                                                                       \
   do                                                                                               \
   {                                                                                                \
@@ -2086,7 +2150,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
     else if constexpr (TD == 3)                                                                    \
       elem_compute<T, N, OP, ATOMIC, NF, GEOM>(in, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB,       \
                                                ldm_l, cf_l, x2_l, cf2_l, gc_l, w3, D_l, wbc, pb,   \
-                                               pc, p, b, c);                                       \
+                                               pc, p, b, c, diag_metric);                          \
     else                                                                                           \
       elem_compute2d<T, N, OP, ATOMIC, NF>(in, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, ldm_l, cf_l,      \
                                            x2_l, cf2_l, p, b, c);                                  \

@@ -125,6 +125,10 @@ class SpectralOperatorData:
     def uses_mfma(self) -> bool:
         return bool(lib().fus_op_uses_mfma(self.h))
 
+    def uses_diag_metric(self) -> bool:
+        """Affine cells with orthogonal edges: stiffness action as three 1-D stiffness contractions (fusmi.h)."""
+        return bool(lib().fus_op_uses_diag_metric(self.h))
+
     def uses_pack32(self) -> bool:
         return bool(lib().fus_op_uses_pack32(self.h))
 

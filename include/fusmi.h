@@ -85,6 +85,8 @@ int fus_synchronize(fus_ctx* ctx);
  * "walk" (0 (default) | 1..8 | -1, any time): block-kernel workgroups per CU that walk several blocks each
  * with the next block's prologue loads in flight under the current block's epilogue; 0 = one workgroup
  * per block (measured faster everywhere so far, profiles/r02_experiments.md), -1 = as many as are resident.
+ * "diag_metric" (1 (default) | 0, before fus_op_create): affine meshes whose cells have mutually orthogonal edges
+ * take the diagonal-metric form of the stiffness kernel (fus_op_uses_diag_metric); 0 keeps the general affine form.
  * "planes" (1 (default) | 0, any time): the shared-dof stage kernel reads the block partial sums of a dof as
  * planes at the dof's own index (no index list; every access coalesced) or through the shared-dof CSR; the
  * sums and their order are the same (CSR is also taken when a dof has more than 16 sharing blocks).
@@ -176,6 +178,11 @@ int fus_op_geometry_mode(fus_op* op);
 /* 1 when the operator's block kernel runs its index-1 / index-2 contractions on the matrix cores
  * (MFMA 16x16x4; degrees 6 and 7 on the per-cell geometry paths, option "mfma"). */
 int fus_op_uses_mfma(fus_op* op);
+/* 1 when the affine kernel runs in its diagonal-metric form: every cell a parallelepiped with mutually orthogonal
+ * edges (boxes in any orientation; J^T J and with it G of spectral_op.hpp:113-130 are diagonal), degrees <= 7 --
+ * the stiffness action as three 1-D stiffness contractions, sum_d g_d (M x K1 x M) x with K1 = D^T diag(w) D,
+ * instead of the six derivative contractions and the pointwise transform (option "diag_metric"). */
+int fus_op_uses_diag_metric(fus_op* op);
 /* 1 when the fp32 stiffness kernel works on two elements per wave in packed float2 (degrees 5-7, per-cell
  * geometry paths, LDS-atomic accumulation; option "pack32"). */
 int fus_op_uses_pack32(fus_op* op);

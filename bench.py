@@ -183,6 +183,8 @@ def torch_exchange(torch, dist, model, rank, loopback=False):
 
 GEOM_NAMES = {"stream": "general, G streamed (6 values per point from HBM: the reference's data path, B_general)",
               "affine": "affine cells (7 values per cell, B_affine)",
+              "affine_diag": "affine cells with orthogonal edges (7 values per cell, B_affine; diagonal metric: three 1-D "
+                             "stiffness contractions per element)",
               "trilinear": "general first-order hexahedra, trilinear (21 values per cell, J and G recomputed per point, "
                            "B_affine + 14 s / N^3 per element-DOF)"}
 
@@ -262,6 +264,8 @@ def main():
                          "or the library's measured default (-1)")
     ap.add_argument("--pack32", type=int, default=None, choices=[-1, 0, 1],
                     help="fp32 degrees 5-7: two elements per wave in packed float2 (1), scalar kernel (0), library default (-1)")
+    ap.add_argument("--diag-metric", type=int, default=None, choices=[0, 1],
+                    help="affine meshes with orthogonal cell edges: diagonal-metric form of the stiffness kernel (default: on)")
     ap.add_argument("--walk", type=int, default=None,
                     help="block-kernel workgroups per CU that walk several blocks each (0: one workgroup per block)")
     ap.add_argument("--lean-rk4", type=int, default=None, choices=[0, 1],
@@ -321,7 +325,8 @@ def main():
         if args.global_cells:
             tail += ["--global-cells", str(args.global_cells)]
         for k, v in (("--block-elems", args.block_elems), ("--waves", args.waves), ("--deterministic", args.deterministic),
-                     ("--mfma", args.mfma), ("--lean-rk4", args.lean_rk4), ("--walk", args.walk), ("--pack32", args.pack32)):
+                     ("--mfma", args.mfma), ("--lean-rk4", args.lean_rk4), ("--walk", args.walk), ("--pack32", args.pack32),
+                     ("--diag-metric", args.diag_metric)):
             if v is not None:
                 tail += [k, str(v)]
         traffic, traffic_src = live_traffic(tail, args.P, args.dtype)
@@ -339,7 +344,8 @@ def main():
     ctx = fa.Context(local_rank, block_elems=args.block_elems, waves=args.waves, deterministic=args.deterministic, geometry=args.geometry)
     if args.graph is not None:
         ctx.set_option("graph", args.graph)
-    for key, val in (("mfma", args.mfma), ("lean_rk4", args.lean_rk4), ("walk", args.walk), ("pack32", args.pack32)):
+    for key, val in (("mfma", args.mfma), ("lean_rk4", args.lean_rk4), ("walk", args.walk), ("pack32", args.pack32),
+                     ("diag_metric", args.diag_metric)):
         if val is not None:
             ctx.set_option(key, val)
     transport = args.transport
@@ -425,6 +431,7 @@ def main():
         info = model.data.info()
         info["mfma"] = model.data.uses_mfma()
         info["pack32"] = model.data.uses_pack32()
+        info["diag_metric"] = model.data.uses_diag_metric()
         affine = model.data.geometry_mode()        # "stream" | "affine" | "trilinear"
         advance(0.0, warmup)
         done = warmup
@@ -473,6 +480,8 @@ def main():
         u = model.u_sol().x.array
         finite = bool(np.isfinite(u).all()) and float(np.abs(u).max()) > 0.0
         model.close()
+        if info["diag_metric"]:
+            affine = "affine_diag"
         return times, prof, info, affine, finite
 
     times, prof, info, affine, finite = run(ctx, args.steps, args.warmup, max(1, args.repeats), not args.no_profile,
@@ -509,7 +518,7 @@ def main():
         # lossy / Westervelt: one more gathered operator input, Westervelt two more vector reads
         extra_x = {"linear": 0, "lossy": 1, "westervelt": 1}[args.model]
         extra_v = {"linear": 0, "lossy": 0, "westervelt": 2}[args.model]
-        geo_b = {"stream": 6 * s, "affine": 7 * s / N3, "trilinear": 21 * s / N3}   # geometry bytes per element-DOF
+        geo_b = {"stream": 6 * s, "affine": 7 * s / N3, "affine_diag": 7 * s / N3, "trilinear": 21 * s / N3}   # geometry bytes per element-DOF
         b_stiff = rho_e * (s + 4 + geo_b[affine] + extra_x * s) + s
         b_general = 4 * (b_stiff + (12 + extra_v) * s)
         n_int = info["interior_dofs"]
@@ -608,7 +617,7 @@ def main():
         for e2, aff2, fin2 in others:
             b2 = 4 * (rho_e * (s + 4 + geo_b[aff2] + extra_x * s) + s + (12 + extra_v) * s)
             v2 = ndofs_global * args.steps / e2
-            key = {"affine": "other_geometry", "trilinear": "trilinear_geometry", "stream": "streamed_geometry"}[aff2]
+            key = {"affine": "other_geometry", "affine_diag": "other_geometry", "trilinear": "trilinear_geometry", "stream": "streamed_geometry"}[aff2]
             out[key] = {"geometry": GEOM_NAMES[aff2], "value": v2, "unit": "DOF-updates/s",
                         "ms_per_step": 1e3 * e2 / args.steps, "algorithmic_bytes_per_dof_update": b2,
                         "frac_of_8TBps": b2 * v2 / world / 8e12, "finite_nonzero_solution": fin2}

@@ -357,11 +357,9 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
     attr_set.fetch_or(dev_bit, std::memory_order_relaxed);
   }
   K.A = op->A;
-  K.A.diag = 0;
-  if (GEOM == GEOM_AFFINE && OP == OP_STIFFNESS && TD == 3 && !MF && !PK && P <= 7 && op->diag)
+  if (GEOM == GEOM_DIAG)
   {
     // the 1-D stiffness matrix K1 = D^T diag(w) D takes the derivative table's place (symmetric: d = dt)
-    K.A.diag = 1;
     for (int q = 0; q < N; ++q)
       for (int i = 0; i < N; ++i)
       {
@@ -463,6 +461,16 @@ static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, 
     }
   }
   // geometry operand: per-cell factors (affine meshes) or the streamed per-point arrays
+  if constexpr (OP == OP_STIFFNESS && P <= 7)
+  {
+    if (op->affine && op->diag)   // cells with orthogonal edges: diagonal-metric form of the stiffness action
+    {
+      const T* gc = static_cast<const T*>(op->d_Gc);
+      return op->deterministic
+                 ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_DIAG>(op, gc, coef, x, bvec, S, b0, nb)
+                 : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_DIAG>(op, gc, coef, x, bvec, S, b0, nb);
+    }
+  }
   if (op->affine)
   {
     const T* gc = static_cast<const T*>(op->d_Gc);

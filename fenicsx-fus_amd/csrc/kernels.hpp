@@ -47,7 +47,6 @@ struct BlockArgs
   int32_t lds_nloc;  // LDS array length (>= max nloc, even)
   int32_t lds_nelem; // LDS per-element table length (>= max elements per block, multiple of 8)
   int32_t waves;
-  int32_t diag;      // affine cells with orthogonal edges: G = diag(g0, g1, g2) w_q (elem_compute, diagonal-metric form)
 };
 
 // Arguments of the fused RK4 stage epilogue of k_block_op (STAGE >= 0): the model vectors in
@@ -192,13 +191,17 @@ enum
 {
   GEOM_STREAM = 0,
   GEOM_AFFINE = 1,
-  GEOM_TRILINEAR = 2
+  GEOM_TRILINEAR = 2,
+  // GEOM_AFFINE data on cells with mutually orthogonal edges (J^T J diagonal): the stiffness action in its
+  // diagonal-metric form (elem_compute); everything else as GEOM_AFFINE
+  GEOM_DIAG = 3
 };
+__host__ __device__ constexpr bool is_aff(int geom) { return geom == GEOM_AFFINE || geom == GEOM_DIAG; }
 
 // numbers per cell held in LDS by the per-cell geometry modes
 __host__ __device__ constexpr int geom_cell_stride(int geom)
 {
-  return geom == GEOM_AFFINE ? 7 : (geom == GEOM_TRILINEAR ? 21 : 0);
+  return is_aff(geom) ? 7 : (geom == GEOM_TRILINEAR ? 21 : 0);
 }
 
 // 1 / x to working precision from the hardware estimate (the per-point G of GEOM_TRILINEAR)
@@ -407,13 +410,13 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
                                              const T* __restrict__ cf_l, const T* __restrict__ x2_l,
                                              const T* __restrict__ cf2_l, const T* __restrict__ gc_l,
                                              const T (&w3)[N], const T* __restrict__ D_l, T wbc, T pb,
-                                             T pc, int p, int b, int c, bool diag = false)
+                                             T pc, int p, int b, int c)
 {
   constexpr int N2 = N * N, Nd = N * N * N;
   constexpr int VW = GLoad<T, N>::VW;
   // GEOM_TRILINEAR keeps the lane's rows / columns of the derivative table in LDS (read where used)
   // so that the kernel fits four waves per SIMD
-  constexpr bool DLDS = (GEOM == GEOM_TRILINEAR) || (GEOM == GEOM_AFFINE && (N == 6 || N == 7));
+  constexpr bool DLDS = (GEOM == GEOM_TRILINEAR) || (is_aff(GEOM) && (N == 6 || N == 7));
   if (in.er < 0)
     return;
   TriLane<T> tri;
@@ -455,7 +458,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
     //   K x = sum_d g_d (M x .. x K1 x .. x M) x,   K1 = D^T diag(w) D  (the 1-D stiffness matrix, in Dk.d here),
     // three contractions instead of six and no pointwise transform.  Index 0 in registers; indices 1 and 2 as in
     // the re-mapped form below: one store of X, the two re-mapped reads, and one store + read per result.
-    if (GEOM == GEOM_AFFINE && diag)
+    if constexpr (GEOM == GEOM_DIAG)
     {
       constexpr int TS = (N == 8 || N == 4) ? N2 + 1 : N2;
       const T g0 = gc_l[in.er * 7 + 0] * cf * wbc, g1 = gc_l[in.er * 7 + 3] * cf * wbc,
@@ -774,7 +777,7 @@ __device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTa
                                                 const T* __restrict__ w_l, const T* __restrict__ pt_l, int p, int b,
                                                 int c)
 {
-  static_assert(GEOM == GEOM_AFFINE || GEOM == GEOM_TRILINEAR, "per-cell geometry kernels");
+  static_assert(is_aff(GEOM) || GEOM == GEOM_TRILINEAR, "per-cell geometry kernels");
   constexpr int N2 = N * N, Nd = N * N * N;
   const bool on = er_ >= 0 && has_col;
   const int er = er_ >= 0 ? er_ : 0;
@@ -954,7 +957,7 @@ __device__ __forceinline__ void elem_compute_pk(int e0, int e1, const DTab<float
                                                 const float* __restrict__ gc_l, const float* __restrict__ w_l,
                                                 const float* __restrict__ pt_l, int p, int b, int c)
 {
-  static_assert(GEOM == GEOM_AFFINE || GEOM == GEOM_TRILINEAR, "per-cell geometry kernels");
+  static_assert(is_aff(GEOM) || GEOM == GEOM_TRILINEAR, "per-cell geometry kernels");
   constexpr int N2 = N * N, Nd = N * N * N;
   constexpr int TS = (N == 8 || N == 4) ? N2 + 1 : N2;   // plane stride of the tile (see elem_compute, REMAP)
   if (e0 < 0)
@@ -1270,7 +1273,7 @@ __device__ __forceinline__ void elem_compute_mfma(const ElemIn<T, N, OP_STIFFNES
                                                   int p, int lane)
 {
   static_assert(N == 7 || N == 8, "one element per wave, table padded to 8");
-  static_assert(GEOM == GEOM_AFFINE || GEOM == GEOM_TRILINEAR, "per-cell geometry kernels");
+  static_assert(is_aff(GEOM) || GEOM == GEOM_TRILINEAR, "per-cell geometry kernels");
   constexpr int N2 = N * N, Nd = N * N * N;
   // one element per wave (EPW = 1): lane 0 always holds it; lanes >= N^2 (N = 7) carry no tensor column
   // but take part in the matrix instructions
@@ -1712,9 +1715,9 @@ __device__ __forceinline__ void load_stage_args(const KArgs<T, N> __attribute__(
 // derivative-table rows read from LDS where used.
 // TD = 2: the same block machinery for quadrilateral elements (Nd = N^2, GEOM_STREAM only).
 template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3, int MF = 0, int PK = 0>
-__global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P >= 8) ? 1 : (P <= 4 && GEOM == GEOM_AFFINE)
+__global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P >= 8) ? 1 : (P <= 4 && is_aff(GEOM))
                                                             ? 4
-                                                            : ((GEOM == GEOM_TRILINEAR || (GEOM == GEOM_AFFINE && P <= 6)) ? FUS_TRI_WAVES(P) : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1)))
+                                                            : ((GEOM == GEOM_TRILINEAR || (is_aff(GEOM) && P <= 6)) ? FUS_TRI_WAVES(P) : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1)))
 k_block_op(const KArgs<T, P + 1> kernel_args)
 {
   (void)kernel_args;
@@ -2108,7 +2111,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
     for (int j = 0; j < N; ++j)
     {
       constexpr bool inreg = (OP == OP_STIFFNESS) && !(FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) && P >= 6)
-                             && GEOM != GEOM_TRILINEAR && !(GEOM == GEOM_AFFINE && (P == 5 || P == 6)) && !MF;
+                             && GEOM != GEOM_TRILINEAR && GEOM != GEOM_DIAG && !(is_aff(GEOM) && (P == 5 || P == 6)) && !MF;
       Drb[j] = inreg ? D_l[b * N + j] : T(0);
       Drc[j] = inreg ? D_l[c * N + j] : T(0);
       Dcb[j] = inreg ? D_l[j * N + b] : T(0);
@@ -2117,7 +2120,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
 #pragma unroll
     for (int a = 0; a < N; ++a)
       w3[a] = (GEOM == GEOM_AFFINE) ? w_l[a] * w_l[b] * w_l[c] : T(0);  // w_q = w_a w_b w_c of this lane's points
-    wbc = (GEOM == GEOM_TRILINEAR || GEOM == GEOM_AFFINE) ? w_l[b] * w_l[c] : T(0);
+    wbc = (GEOM == GEOM_TRILINEAR || GEOM == GEOM_DIAG) ? w_l[b] * w_l[c] : T(0);
     pb = (GEOM == GEOM_TRILINEAR) ? pt_l[b] : T(0), pc = (GEOM == GEOM_TRILINEAR) ? pt_l[c] : T(0);
   }
 
@@ -2136,8 +2139,6 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   for (int i = 0; i < N; ++i)
     Dk.w[i] = qt->Dk.w[i], Dk.x[i] = qt->Dk.x[i];
   const T* __restrict__ geo = qt->geo;
-  const bool diag_metric = (GEOM == GEOM_AFFINE && OP == OP_STIFFNESS && TD == 3 && !MF && !PK && LPE == 64) && qt->A.diag != 0;
-  (void)diag_metric;
 #define FUS_ELEM_COMPUTE(in)                                                                       \
   do                                                                                               \
   {                                                                                                \
@@ -2150,7 +2151,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
     else if constexpr (TD == 3)                                                                    \
       elem_compute<T, N, OP, ATOMIC, NF, GEOM>(in, Dk, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, sB,       \
                                                ldm_l, cf_l, x2_l, cf2_l, gc_l, w3, D_l, wbc, pb,   \
-                                               pc, p, b, c, diag_metric);                          \
+                                               pc, p, b, c);                                       \
     else                                                                                           \
       elem_compute2d<T, N, OP, ATOMIC, NF>(in, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, ldm_l, cf_l,      \
                                            x2_l, cf2_l, p, b, c);                                  \

@@ -657,15 +657,17 @@ static int ensure_stream_geometry(fus_op* op)
   return FUS_OK;
 }
 
-// Measured choice (MI355X, profiles/r02_mfma.md) between the vector and the matrix-core form of the
-// index-1 / index-2 contractions.
+// Measured choice (MI355X, profiles/r02_experiments.md sections 5 and 15) between the vector and the matrix-core
+// form of the index-1 / index-2 contractions.
 static bool mfma_default(int P, bool f64, bool affine)
 {
-  // degree 7, fp64, trilinear geometry: block kernel 1.62 -> 1.53 ms per launch at 64^3 (-5.8 %; the vector
-  // ALUs, busy with the per-point Jacobians, are what the matrix cores relieve).  Slower everywhere else:
-  // affine geometry at degree 7 (+6 %: its vector work is small), fp32 at degree 6 (+45 %: the f32 MFMA
-  // issues at the vector rate and half of every 16 x 16 x 4 tile is padding).
-  return P == 7 && f64 && !affine;
+  // Nowhere at present.  Degree 7, fp64, trilinear geometry was the one case where the matrix-core form won
+  // (-5.8 % against the tile-read vector form); with the re-mapped vector contractions at N = 8 (derivative-table
+  // rows by scalar loads) the vector form is 2.7 % ahead: 1.423 against 1.469 ms per launch at 64^3.  Affine
+  // geometry at degree 7 (+6 %: little vector work to relieve) and fp32 at degree 6 (+45 %: the f32 MFMA issues
+  // at the vector-FMA rate) were slower from the start.  Option "mfma" = 1 still selects the variants.
+  (void)P, (void)f64, (void)affine;
+  return false;
 }
 
 template <typename T, int P>

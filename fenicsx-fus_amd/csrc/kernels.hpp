@@ -451,9 +451,11 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
     // them), contracts with the derivative table in scalar registers and writes the result back for
     // the (b, c) owner: 5 reads + 5 writes + 5 reads per direction instead of 25 reads + the lane's
     // derivative rows -- the element trips of the per-cell geometry kernels are bound by the LDS port.
-    // Per-cell geometry kernels up to degree 6: degree 7 (N = 8) keeps the tile-read form (re-mapped it
-    // measured 5-14 % slower), and so does the streamed kernel (+1.5 % only: it sits on the bandwidth roof).
-    constexpr bool REMAP = GEOM != GEOM_STREAM && N <= 7;
+    // Per-cell geometry kernels of every degree up to 7 (N = 8: since the derivative-table rows come by scalar
+    // loads, dtab_row, the re-mapped form is 3-17 % faster than the tile reads there too and 3 % faster than
+    // the matrix-core form; in round 1, table in registers, it was 5-14 % slower); the streamed kernel keeps the
+    // tile reads (+1.5 % only: it sits on the bandwidth roof).
+    constexpr bool REMAP = GEOM != GEOM_STREAM && N <= 8;
     // Diagonal metric (affine cells with mutually orthogonal edges -- boxes in any orientation): G(q) = diag(g) w_q, so
     //   K x = sum_d g_d (M x .. x K1 x .. x M) x,   K1 = D^T diag(w) D  (the 1-D stiffness matrix, in Dk.d here),
     // three contractions instead of six and no pointwise transform.  Index 0 in registers; indices 1 and 2 as in

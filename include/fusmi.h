@@ -78,7 +78,8 @@ int fus_synchronize(fus_ctx* ctx);
  * "mfma" (-1 auto (default) | 0 | 1, before fus_op_create): degrees 6 and 7 on the per-cell geometry
  * paths -- the index-1 / index-2 contractions of an element, the (N x N).(N x N^2) products of the
  * reference's contract<> (sum_factorisation.hpp:70-86), as 16x16x4 MFMA tiles on the matrix cores
- * instead of vector FMAs.  Auto = where it measured faster on MI355X (degree 7, fp64, trilinear geometry).
+ * instead of vector FMAs.  Auto = where it measures faster on MI355X: nowhere at present (the re-mapped vector form is
+ * 3 % ahead of it at degree 7, fp64, trilinear geometry, the one case it used to win; profiles/r02_experiments.md).
  * "pack32" (-1 auto (default) | 0 | 1, before fus_op_create): fp32, degrees 5-7, per-cell geometry paths -- a
  * wave works on two elements at once, every tile exchange and FMA packed as float2 (half the LDS and vector
  * instructions per element of the scalar fp32 kernel, which is LDS bound).

@@ -1374,7 +1374,7 @@ static int stage_end(fus_model* m, int i, double t, double dt)
   }
   const LeanRK<T> R{(T)sc.b0dt, (T)sc.r0, (T)sc.r1};
   const int kind = stage_kind(m, i);
-  if (nloc > 0 && c->planes && (int)op->L.plane_cnt.size() <= FUS_MAX_PLANES)
+  if (nloc > 0 && c->planes && (int)op->L.plane_cnt.size() <= (c->planes == 1 ? FUS_MAX_PLANES : c->planes))
   {
     ProfScope ps(c, "stage");
     const dim3 grid(nblk(nloc)), blk(256);
@@ -1957,7 +1957,11 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
     c->pack32 = (int)value;
   }
   else if (!strcmp(key, "planes"))
-    c->planes = value != 0;
+  {
+    if (value < 0 || value > FUS_MAX_PLANES)
+      return fail(FUS_ERR_ARG, "planes must be 0 (CSR form), 1 (planes) or 2..16 (planes for meshes with at most so many sharers of a dof)");
+    c->planes = (int)value;
+  }
   else if (!strcmp(key, "diag_metric"))
     c->diag_metric = value != 0;
   else if (!strcmp(key, "walk"))

@@ -88,9 +88,10 @@ int fus_synchronize(fus_ctx* ctx);
  * per block (measured faster everywhere so far, profiles/r02_experiments.md), -1 = as many as are resident.
  * "diag_metric" (1 (default) | 0, before fus_op_create): affine meshes whose cells have mutually orthogonal edges
  * take the diagonal-metric form of the stiffness kernel (fus_op_uses_diag_metric); 0 keeps the general affine form.
- * "planes" (1 (default) | 0, any time): the shared-dof stage kernel reads the block partial sums of a dof as
+ * "planes" (1 (default) | 0 | 2..16, any time): the shared-dof stage kernel reads the block partial sums of a dof as
  * planes at the dof's own index (no index list; every access coalesced) or through the shared-dof CSR; the
- * sums and their order are the same (CSR is also taken when a dof has more than 16 sharing blocks).
+ * sums and their order are the same.  The CSR form is also taken when a dof has more sharing blocks than the
+ * kernel has planes (16; a value k = 2..16 lowers that limit to k).
  * Unknown keys -> FUS_ERR_ARG. */
 int fus_set_option(fus_ctx* ctx, const char* key, int64_t value);
 

@@ -713,7 +713,8 @@ def test_shared_stage_planes_and_csr_agree_bitwise(orc, block_elems, P, kind):
         orc.lossy_rk4(3, pr.N, pr.dm, pr.G, pr.D, lin, att, m, src, absb, src2, 0.5e6, 6e4, 1500.0, 0.0, tf, dt, u, v)
     assert np.abs(u).max() > 0
     outs = {}
-    for planes in (1, 0):
+    # (4: a plane limit below the 8 sharers of a vertex of one-element blocks -> the CSR form is taken by itself)
+    for planes in (1, 0, 4):
         kw = {} if block_elems is None else {"block_elems": block_elems}
         cx = fa.Context(0, deterministic=1, **kw)
         cx.set_option("planes", planes)
@@ -728,3 +729,4 @@ def test_shared_stage_planes_and_csr_agree_bitwise(orc, block_elems, P, kind):
         model.close()
         cx.close()
     assert np.array_equal(outs[1][0], outs[0][0]) and np.array_equal(outs[1][1], outs[0][1])
+    assert np.array_equal(outs[4][0], outs[0][0]) and np.array_equal(outs[4][1], outs[0][1])

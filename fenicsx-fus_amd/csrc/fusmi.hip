@@ -1813,7 +1813,7 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   const int be_tri = hi32 ? 16 : be_affine;
   const int be0 = c->block_elems > 0
                       ? c->block_elems
-                      : ((trilinear_mesh || affine_mesh) && op->P == 4 && op->dtype == FUS_F64 && op->nfields == 1 && c->waves <= 0) ? 32
+                      : ((trilinear_mesh || affine_mesh) && op->P == 4 && op->nfields == 1 && c->waves <= 0) ? 32
                       : (two_per_cu ? be_two[op->P]
                                     : (trilinear_mesh ? be_tri : (affine_mesh ? be_affine : be_stream)));
   const size_t lds_cap = two_per_cu ? 80 * 1024 : 160 * 1024;
@@ -1823,8 +1823,9 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   // per-cell geometry paths at p = 4 in fp64: 32 elements / 8 waves (two 8-wave blocks per CU) leave fewer
   // shared dofs than 16 / 4 -- the block kernel is 2-6 % slower, the step 1.5-3 % faster
   // (one operator input only: with two, such a block takes 92 KB of LDS and a CU holds one)
-  const bool tri_p4 = (trilinear_mesh || affine_mesh) && op->P == 4 && op->dtype == FUS_F64 && op->nfields == 1
-                      && c->waves <= 0 && c->block_elems <= 0;
+  // (fp32: the same 32 elements, +7-8 % over 24; eight waves on affine cells, four on the trilinear kernel)
+  const bool tri_p4 = (trilinear_mesh || affine_mesh) && op->P == 4 && op->nfields == 1 && c->waves <= 0
+                      && c->block_elems <= 0 && (op->dtype == FUS_F64 || affine_mesh);
   if (tri_p4)
     waves = 8;
   // blocks must fit the LDS budget (the CU's 160 KB, or half of it): shrink the block until they do

@@ -113,10 +113,17 @@ struct DTab
 // keep the whole table in scalar registers (k_block_op copies it there before the trips): per-row loads
 // measured 3-6 % slower at degree 6 (also with rows padded to one load each) and degree 5.
 // Only callable from k_block_op (whose only argument starts with BlockArgs, then the DTab: KArgs).
+// rows by scalar loads where the table does not fit the scalar registers: fp64 from N = 8, every type from N = 9
+template <typename T, int N>
+__host__ __device__ constexpr bool dtab_by_rows()
+{
+  return N >= 9 || (sizeof(T) == 8 && N == 8);
+}
+
 template <typename T, int N, int TR>
 __device__ __forceinline__ void dtab_row(const DTab<T, N>& Dk, int r, T (&out)[N])
 {
-  if constexpr (sizeof(T) == 8 && N == 8)
+  if constexpr (dtab_by_rows<T, N>())
   {
     typedef const T __attribute__((address_space(4))) * CP;
     typedef const char __attribute__((address_space(4))) * CC;
@@ -768,8 +775,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 // plane has more than 64 columns, so an element is worked on by TWO waves (lane pair index p = 0..127,
 // columns p < N^2), the exchanges through the element's LDS tile are fenced by workgroup barriers instead
 // of wave barriers, and nothing returns early (every wave of the workgroup meets every barrier; `on` guards
-// the memory operations of lanes without an element or a column).  Tile-read form of the index-1 / index-2
-// contractions with the derivative table read from LDS; per-cell geometry (affine / trilinear).
+// the memory operations of lanes without an element or a column).  Per-cell geometry (affine / trilinear).
 template <typename T, int N, int OP, int ATOMIC, int NF, int GEOM>
 __device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTab<T, N>& Dk, const T* __restrict__ x_l,
                                                 T* __restrict__ y_l, T* __restrict__ sA,
@@ -813,104 +819,257 @@ __device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTa
       for (int a = 0; a < N; ++a)
         X[a] = x_l[li[a]];
     }
-    // derivative along tensor index 0: registers only (spectral_op.hpp:194-196)
-    // (scheduling fences keep the table reads of one output at a time in registers: with everything
-    // unrolled and hoisted these kernels spill at the 256-register cap)
-#pragma unroll
-    for (int q = 0; q < N; ++q)
+    // Two forms of the index-1 / index-2 contractions.  Re-mapped (as elem_compute; table rows by scalar loads): the
+    // faster one on affine cells at p = 8 (fp64 5.9 -> 9.3e9 DOF-updates/s, fp32 +10 %) and at p = 9 in fp32 (+10 %).
+    // Tile reads with the table in LDS: everywhere else (the re-mapped form measured 4-12 % slower there: its 14
+    // workgroup barriers per element against 6).
+    constexpr bool REMAP_HI = is_aff(GEOM) && (N == 9 || (N == 10 && sizeof(T) == 4));
+    if constexpr (REMAP_HI)
     {
-      T acc = T(0);
-#pragma unroll
-      for (int i = 0; i < N; ++i)
-        acc += D_l[q * N + i] * X[i];
-      F0[q] = acc;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (on)
-    {
-#pragma unroll
-      for (int a = 0; a < N; ++a)
-        sA[a * N2 + pp] = X[a];
-    }
-    __syncthreads();
-    // derivatives along tensor indices 1 and 2 (spectral_op.hpp:199-210)
-#pragma unroll
-    for (int a = 0; a < N; ++a)
-      F1[a] = F2[a] = T(0);
-#pragma unroll 1
-    for (int j = 0; j < N; ++j)
-    {
-      const T d1 = D_l[bb * N + j], d2 = D_l[cc * N + j];
-#pragma unroll
-      for (int a = 0; a < N; ++a)
-      {
-        F1[a] += d1 * sA[a * N2 + j * N + cc];
-        F2[a] += d2 * sA[a * N2 + bb * N + j];
-      }
-    }
-    // stiffness::transform (spectral_op.hpp:113-130)
-#pragma unroll
-    for (int a = 0; a < N; ++a)
-    {
-      if (GEOM == GEOM_TRILINEAR)
-        tri.transform(pt_l[a], w_l[a] * wbc * cf, F0[a], F1[a], F2[a]);
-      else
-      {
-        const T w3 = w_l[a] * w_l[bb] * w_l[cc];
-        T G6[6];
-#pragma unroll
-        for (int gi = 0; gi < 6; ++gi)
-          G6[gi] = gc_l[er * 7 + gi] * w3;   // affine cell: G(q) = Gc w_q
-        const T w0 = F0[a], w1 = F1[a], w2 = F2[a];
-        F0[a] = cf * (G6[0] * w0 + G6[1] * w1 + G6[2] * w2);
-        F1[a] = cf * (G6[1] * w0 + G6[3] * w1 + G6[4] * w2);
-        F2[a] = cf * (G6[2] * w0 + G6[4] * w1 + G6[5] * w2);
-      }
-    }
-    // transposed contractions (spectral_op.hpp:222-238)
-    __syncthreads();
-    if (on)
-    {
-#pragma unroll
-      for (int a = 0; a < N; ++a)
-        sA[a * N2 + pp] = F1[a];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int a = 0; a < N; ++a)
-    {
-      T acc = T(0);
-#pragma unroll
+      // Re-mapped form of the index-1 / index-2 contractions (as elem_compute): lane pair (b, c) re-reads the tile as
+      // (a' = b, c) with index 1 along its registers, then as (a' = b, b' = c) with index 2 along them; derivative-table
+      // rows by scalar loads (dtab_row); every exchange fenced by a workgroup barrier (two waves share the element).
+      constexpr int TS = N2 + 1;   // N planes of N^2 + 1: exactly the Nd + N entries of an element slot
+      T Tb[N], Uc[N];
+  #pragma unroll
       for (int q = 0; q < N; ++q)
-        acc += D_l[q * N + a] * F0[q];
-      Y[a] = acc;
-      __builtin_amdgcn_sched_barrier(0);
-    }
-#pragma unroll 1
-    for (int j = 0; j < N; ++j)
-    {
-      const T d1 = D_l[j * N + bb];
-#pragma unroll
+      {
+        T acc = T(0), dr[N];
+        dtab_row<T, N, 0>(Dk, q, dr);
+  #pragma unroll
+        for (int i = 0; i < N; ++i)
+          acc += dr[i] * X[i];
+        F0[q] = acc;
+      }
+      if (on)
+      {
+  #pragma unroll
+        for (int a = 0; a < N; ++a)
+          sA[a * TS + pp] = X[a];
+      }
+      __syncthreads();
+  #pragma unroll
+      for (int k = 0; k < N; ++k)
+      {
+        Tb[k] = sA[bb * TS + k * N + cc];
+        Uc[k] = sA[bb * TS + cc * N + k];
+      }
+      __syncthreads();
+  #pragma unroll
+      for (int q = 0; q < N; ++q)
+      {
+        T acc = T(0), dr[N];
+        dtab_row<T, N, 0>(Dk, q, dr);
+  #pragma unroll
+        for (int k = 0; k < N; ++k)
+          acc += dr[k] * Tb[k];
+        if (on)
+          sA[bb * TS + q * N + cc] = acc;   // d/dX1 at point (b, q, c)
+      }
+      __syncthreads();
+  #pragma unroll
       for (int a = 0; a < N; ++a)
-        Y[a] += d1 * sA[a * N2 + j * N + cc];
-    }
-    __syncthreads();
-    if (on)
-    {
-#pragma unroll
+        F1[a] = sA[a * TS + pp];
+      __syncthreads();
+  #pragma unroll
+      for (int q = 0; q < N; ++q)
+      {
+        T acc = T(0), dr[N];
+        dtab_row<T, N, 0>(Dk, q, dr);
+  #pragma unroll
+        for (int k = 0; k < N; ++k)
+          acc += dr[k] * Uc[k];
+        if (on)
+          sA[bb * TS + cc * N + q] = acc;   // d/dX2 at point (b, c, q)
+      }
+      __syncthreads();
+  #pragma unroll
       for (int a = 0; a < N; ++a)
-        sA[a * N2 + pp] = F2[a];
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int j = 0; j < N; ++j)
-    {
-      const T d2 = D_l[j * N + cc];
-#pragma unroll
+        F2[a] = sA[a * TS + pp];
+      // stiffness::transform (spectral_op.hpp:113-130)
+  #pragma unroll
       for (int a = 0; a < N; ++a)
-        Y[a] += d2 * sA[a * N2 + bb * N + j];
+      {
+        if (GEOM == GEOM_TRILINEAR)
+          tri.transform(pt_l[a], w_l[a] * wbc * cf, F0[a], F1[a], F2[a]);
+        else
+        {
+          const T w3 = w_l[a] * w_l[bb] * w_l[cc];
+          T G6[6];
+  #pragma unroll
+          for (int gi = 0; gi < 6; ++gi)
+            G6[gi] = gc_l[er * 7 + gi] * w3;   // affine cell: G(q) = Gc w_q
+          const T w0 = F0[a], w1 = F1[a], w2 = F2[a];
+          F0[a] = cf * (G6[0] * w0 + G6[1] * w1 + G6[2] * w2);
+          F1[a] = cf * (G6[1] * w0 + G6[3] * w1 + G6[4] * w2);
+          F2[a] = cf * (G6[2] * w0 + G6[4] * w1 + G6[5] * w2);
+        }
+      }
+      // transposed contractions (spectral_op.hpp:222-238), the same way round
+      __syncthreads();
+      if (on)
+      {
+  #pragma unroll
+        for (int a = 0; a < N; ++a)
+          sA[a * TS + pp] = F1[a];
+      }
+      __syncthreads();
+  #pragma unroll
+      for (int k = 0; k < N; ++k)
+        Tb[k] = sA[bb * TS + k * N + cc];
+      __syncthreads();
+  #pragma unroll
+      for (int j = 0; j < N; ++j)
+      {
+        T acc = T(0), dc[N];
+        dtab_row<T, N, 1>(Dk, j, dc);
+  #pragma unroll
+        for (int q = 0; q < N; ++q)
+          acc += dc[q] * Tb[q];
+        if (on)
+          sA[bb * TS + j * N + cc] = acc;
+      }
+      __syncthreads();
+  #pragma unroll
+      for (int a = 0; a < N; ++a)
+      {
+        T acc = sA[a * TS + pp], dc[N];
+        dtab_row<T, N, 1>(Dk, a, dc);
+  #pragma unroll
+        for (int q = 0; q < N; ++q)
+          acc += dc[q] * F0[q];
+        Y[a] = acc;
+      }
+      __syncthreads();
+      if (on)
+      {
+  #pragma unroll
+        for (int a = 0; a < N; ++a)
+          sA[a * TS + pp] = F2[a];
+      }
+      __syncthreads();
+  #pragma unroll
+      for (int k = 0; k < N; ++k)
+        Uc[k] = sA[bb * TS + cc * N + k];
+      __syncthreads();
+  #pragma unroll
+      for (int j = 0; j < N; ++j)
+      {
+        T acc = T(0), dc[N];
+        dtab_row<T, N, 1>(Dk, j, dc);
+  #pragma unroll
+        for (int q = 0; q < N; ++q)
+          acc += dc[q] * Uc[q];
+        if (on)
+          sA[bb * TS + cc * N + j] = acc;
+      }
+      __syncthreads();
+  #pragma unroll
+      for (int a = 0; a < N; ++a)
+        Y[a] += sA[a * TS + pp];
+      __syncthreads();   // the tile is free for the next element
     }
-    __syncthreads();   // the tile is free for the next element
+    else
+    {
+      // derivative along tensor index 0: registers only (spectral_op.hpp:194-196)
+      // (scheduling fences keep the table reads of one output at a time in registers: with everything
+      // unrolled and hoisted these kernels spill at the 256-register cap)
+  #pragma unroll
+      for (int q = 0; q < N; ++q)
+      {
+        T acc = T(0);
+  #pragma unroll
+        for (int i = 0; i < N; ++i)
+          acc += D_l[q * N + i] * X[i];
+        F0[q] = acc;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (on)
+      {
+  #pragma unroll
+        for (int a = 0; a < N; ++a)
+          sA[a * N2 + pp] = X[a];
+      }
+      __syncthreads();
+      // derivatives along tensor indices 1 and 2 (spectral_op.hpp:199-210)
+  #pragma unroll
+      for (int a = 0; a < N; ++a)
+        F1[a] = F2[a] = T(0);
+  #pragma unroll 1
+      for (int j = 0; j < N; ++j)
+      {
+        const T d1 = D_l[bb * N + j], d2 = D_l[cc * N + j];
+  #pragma unroll
+        for (int a = 0; a < N; ++a)
+        {
+          F1[a] += d1 * sA[a * N2 + j * N + cc];
+          F2[a] += d2 * sA[a * N2 + bb * N + j];
+        }
+      }
+      // stiffness::transform (spectral_op.hpp:113-130)
+  #pragma unroll
+      for (int a = 0; a < N; ++a)
+      {
+        if (GEOM == GEOM_TRILINEAR)
+          tri.transform(pt_l[a], w_l[a] * wbc * cf, F0[a], F1[a], F2[a]);
+        else
+        {
+          const T w3 = w_l[a] * w_l[bb] * w_l[cc];
+          T G6[6];
+  #pragma unroll
+          for (int gi = 0; gi < 6; ++gi)
+            G6[gi] = gc_l[er * 7 + gi] * w3;   // affine cell: G(q) = Gc w_q
+          const T w0 = F0[a], w1 = F1[a], w2 = F2[a];
+          F0[a] = cf * (G6[0] * w0 + G6[1] * w1 + G6[2] * w2);
+          F1[a] = cf * (G6[1] * w0 + G6[3] * w1 + G6[4] * w2);
+          F2[a] = cf * (G6[2] * w0 + G6[4] * w1 + G6[5] * w2);
+        }
+      }
+      // transposed contractions (spectral_op.hpp:222-238)
+      __syncthreads();
+      if (on)
+      {
+  #pragma unroll
+        for (int a = 0; a < N; ++a)
+          sA[a * N2 + pp] = F1[a];
+      }
+      __syncthreads();
+  #pragma unroll
+      for (int a = 0; a < N; ++a)
+      {
+        T acc = T(0);
+  #pragma unroll
+        for (int q = 0; q < N; ++q)
+          acc += D_l[q * N + a] * F0[q];
+        Y[a] = acc;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  #pragma unroll 1
+      for (int j = 0; j < N; ++j)
+      {
+        const T d1 = D_l[j * N + bb];
+  #pragma unroll
+        for (int a = 0; a < N; ++a)
+          Y[a] += d1 * sA[a * N2 + j * N + cc];
+      }
+      __syncthreads();
+      if (on)
+      {
+  #pragma unroll
+        for (int a = 0; a < N; ++a)
+          sA[a * N2 + pp] = F2[a];
+      }
+      __syncthreads();
+  #pragma unroll 1
+      for (int j = 0; j < N; ++j)
+      {
+        const T d2 = D_l[j * N + cc];
+  #pragma unroll
+        for (int a = 0; a < N; ++a)
+          Y[a] += d2 * sA[a * N2 + bb * N + j];
+      }
+      __syncthreads();   // the tile is free for the next element
+    }
   }
   else
   {
@@ -2131,7 +2290,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   // derivative table (N = 8 in fp64: read row by row where used, dtab_row), 1-D weights and points -> scalar
   // registers for the trips
   DTab<T, N> Dk;
-  if constexpr (!(sizeof(T) == 8 && N == 8))
+  if constexpr (!dtab_by_rows<T, N>())
   {
 #pragma unroll
     for (int i = 0; i < N * N; ++i)

@@ -408,6 +408,20 @@ __device__ __forceinline__ void elem_compute2d(const ElemIn<T, N, OP, GEOM_STREA
     y_l[li] += Y;
 }
 
+// Index of entry (i0, i1, i2) of an element's exchange tile in the re-mapped contractions.  N = 8: the tile is read and
+// written by lane (b, c) as (a, b, c) for every a, as (b, k, c) for every k and as (b, c, k) for every k; with a linear
+// image two of the three patterns put the 32 lanes of an LDS lane group on 4-8 banks (42 % of the LDS cycles of the
+// p=7 kernels were bank conflicts, profiles/r02_p7_remap_counters.json).  XOR-ing index 1 with the low bits of index
+// 0 and index 2 with index 1 makes all three conflict free, without padding.  Other N: planes of TS entries.
+template <int N, int TS>
+__device__ __forceinline__ int rtix(int i0, int i1, int i2)
+{
+  if constexpr (N == 8)
+    return i0 * 64 + ((i1 ^ (i0 & 3)) << 3) + (i2 ^ i1);
+  else
+    return i0 * TS + i1 * N + i2;
+}
+
 template <typename T, int N, int OP, int ATOMIC, int NF, int GEOM>
 __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, const DTab<T, N>& Dk,
                                              const T (&Drb)[N], const T (&Drc)[N], const T (&Dcb)[N],
@@ -484,14 +498,14 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
       }
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        sA[a * TS + p] = X[a];
+        sA[rtix<N, TS>(a, b, c)] = X[a];
       FUS_WAVE_SYNC();
       T Tb[N], Uc[N];
 #pragma unroll
       for (int k = 0; k < N; ++k)
       {
-        Tb[k] = sA[b * TS + k * N + c];
-        Uc[k] = sA[b * TS + c * N + k];
+        Tb[k] = sA[rtix<N, TS>(b, k, c)];
+        Uc[k] = sA[rtix<N, TS>(b, c, k)];
       }
       FUS_WAVE_SYNC();
 #pragma unroll
@@ -502,12 +516,12 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
         for (int k = 0; k < N; ++k)
           acc += kr[k] * Tb[k];
-        sA[b * TS + q * N + c] = g1 * acc;   // index-1 term at point (b, q, c)
+        sA[rtix<N, TS>(b, q, c)] = g1 * acc;   // index-1 term at point (b, q, c)
       }
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        Y[a] += sA[a * TS + p];
+        Y[a] += sA[rtix<N, TS>(a, b, c)];
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int q = 0; q < N; ++q)
@@ -517,12 +531,12 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
         for (int k = 0; k < N; ++k)
           acc += kr[k] * Uc[k];
-        sA[b * TS + c * N + q] = g2 * acc;   // index-2 term at point (b, c, q)
+        sA[rtix<N, TS>(b, c, q)] = g2 * acc;   // index-2 term at point (b, c, q)
       }
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        Y[a] += sA[a * TS + p];
+        Y[a] += sA[rtix<N, TS>(a, b, c)];
     }
     else if constexpr (REMAP)
     {
@@ -541,14 +555,14 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
       }
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        sA[a * TS + p] = X[a];
+        sA[rtix<N, TS>(a, b, c)] = X[a];
       FUS_WAVE_SYNC();
       T Tb[N], Uc[N];
 #pragma unroll
       for (int k = 0; k < N; ++k)
       {
-        Tb[k] = sA[b * TS + k * N + c];
-        Uc[k] = sA[b * TS + c * N + k];
+        Tb[k] = sA[rtix<N, TS>(b, k, c)];
+        Uc[k] = sA[rtix<N, TS>(b, c, k)];
       }
       FUS_WAVE_SYNC();
 #pragma unroll
@@ -559,12 +573,12 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
         for (int k = 0; k < N; ++k)
           acc += dr[k] * Tb[k];
-        sA[b * TS + q * N + c] = acc;  // d/dX1 at point (b, q, c)
+        sA[rtix<N, TS>(b, q, c)] = acc;  // d/dX1 at point (b, q, c)
       }
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        F1[a] = sA[a * TS + p];
+        F1[a] = sA[rtix<N, TS>(a, b, c)];
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int q = 0; q < N; ++q)
@@ -574,12 +588,12 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
         for (int k = 0; k < N; ++k)
           acc += dr[k] * Uc[k];
-        sA[b * TS + c * N + q] = acc;  // d/dX2 at point (b, c, q)
+        sA[rtix<N, TS>(b, c, q)] = acc;  // d/dX2 at point (b, c, q)
       }
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        F2[a] = sA[a * TS + p];
+        F2[a] = sA[rtix<N, TS>(a, b, c)];
       // stiffness::transform (spectral_op.hpp:113-130)
 #pragma unroll
       for (int a = 0; a < N; ++a)
@@ -605,11 +619,11 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        sA[a * TS + p] = F1[a];
+        sA[rtix<N, TS>(a, b, c)] = F1[a];
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int k = 0; k < N; ++k)
-        Tb[k] = sA[b * TS + k * N + c];
+        Tb[k] = sA[rtix<N, TS>(b, k, c)];
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int j = 0; j < N; ++j)
@@ -619,13 +633,13 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
         for (int q = 0; q < N; ++q)
           acc += dc[q] * Tb[q];
-        sA[b * TS + j * N + c] = acc;
+        sA[rtix<N, TS>(b, j, c)] = acc;
       }
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
       {
-        T acc = sA[a * TS + p], dc[N];
+        T acc = sA[rtix<N, TS>(a, b, c)], dc[N];
         dtab_row<T, N, 1>(Dk, a, dc);
 #pragma unroll
         for (int q = 0; q < N; ++q)
@@ -635,11 +649,11 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        sA[a * TS + p] = F2[a];
+        sA[rtix<N, TS>(a, b, c)] = F2[a];
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int k = 0; k < N; ++k)
-        Uc[k] = sA[b * TS + c * N + k];
+        Uc[k] = sA[rtix<N, TS>(b, c, k)];
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int j = 0; j < N; ++j)
@@ -649,12 +663,12 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
         for (int q = 0; q < N; ++q)
           acc += dc[q] * Uc[q];
-        sA[b * TS + c * N + j] = acc;
+        sA[rtix<N, TS>(b, c, j)] = acc;
       }
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
-        Y[a] += sA[a * TS + p];
+        Y[a] += sA[rtix<N, TS>(a, b, c)];
     }
     else
     {

@@ -413,6 +413,21 @@ __device__ __forceinline__ void elem_compute2d(const ElemIn<T, N, OP, GEOM_STREA
 // image two of the three patterns put the 32 lanes of an LDS lane group on 4-8 banks (42 % of the LDS cycles of the
 // p=7 kernels were bank conflicts, profiles/r02_p7_remap_counters.json).  XOR-ing index 1 with the low bits of index
 // 0 and index 2 with index 1 makes all three conflict free, without padding.  Other N: planes of TS entries.
+// Plane stride of the exchange tile in the re-mapped contractions, and the entries reserved per element slot
+// (Layout::lds_bytes reserves the same).  N = 4: one entry of padding per plane; N = 8: XOR swizzle, no padding (rtix);
+// fp32 at N = 7 (the LDS-bound kernel of BASELINE configs[4]): planes of 56 -- 63 -> 56 bank-conflict cycles per element
+// over the three read patterns, by enumeration (ideal 42).
+template <typename T, int N>
+__host__ __device__ constexpr int tile_plane_stride()
+{
+  return (N == 8 || N == 4) ? N * N + 1 : ((N == 7 && sizeof(T) == 4) ? 56 : N * N);
+}
+template <typename T, int N, int TD>
+__host__ __device__ constexpr int tile_slot_entries()
+{
+  return (TD == 3 && N == 7 && sizeof(T) == 4) ? N * 56 : (TD == 3 ? N * N * N : N * N) + N;
+}
+
 template <int N, int TS>
 __device__ __forceinline__ int rtix(int i0, int i1, int i2)
 {
@@ -483,7 +498,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
     // the re-mapped form below: one store of X, the two re-mapped reads, and one store + read per result.
     if constexpr (GEOM == GEOM_DIAG)
     {
-      constexpr int TS = (N == 8 || N == 4) ? N2 + 1 : N2;
+      constexpr int TS = tile_plane_stride<T, N>();
       const T g0 = gc_l[in.er * 7 + 0] * cf * wbc, g1 = gc_l[in.er * 7 + 3] * cf * wbc,
               g2 = gc_l[in.er * 7 + 5] * cf * wbc;   // w_b w_c of the lane's column, whichever two indices it spans
 #pragma unroll
@@ -542,7 +557,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
     {
       // plane stride of the tile: N^2, padded by one where the re-mapped accesses (lanes (b, c) at
       // b * TS + ...) would otherwise fall on the same LDS banks for every b (N = 8: 8-way, N = 4: 2-way)
-      constexpr int TS = (N == 8 || N == 4) ? N2 + 1 : N2;
+      constexpr int TS = tile_plane_stride<T, N>();
 #pragma unroll
       for (int q = 0; q < N; ++q)
       {
@@ -1134,7 +1149,7 @@ __device__ __forceinline__ void elem_compute_pk(int e0, int e1, const DTab<float
 {
   static_assert(is_aff(GEOM) || GEOM == GEOM_TRILINEAR, "per-cell geometry kernels");
   constexpr int N2 = N * N, Nd = N * N * N;
-  constexpr int TS = (N == 8 || N == 4) ? N2 + 1 : N2;   // plane stride of the tile (see elem_compute, REMAP)
+  constexpr int TS = (N == 8 || N == 4) ? N2 + 1 : N2;   // plane stride of the tile of float2 entries (see elem_compute, REMAP)
   if (e0 < 0)
     return;
   const bool two = e1 >= 0;
@@ -1906,6 +1921,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   // lanes that work on one element slot group: a wave, or two waves where a tensor plane has more than
   // 64 columns (degrees 8-10, elem_compute_hi)
   constexpr int LPE = (N2 <= 64) ? 64 : 128;
+  constexpr int SLOT = tile_slot_entries<T, N, TD>();   // entries of one element's exchange tile
   static_assert(N2 <= 128, "degrees up to 10");
   static_assert(LPE == 64 || (TD == 3 && GEOM != GEOM_STREAM && !MF), "degrees 8-10: hexahedra, per-cell geometry");
   // packed fp32 (elem_compute_pk): a wave works on two elements at once
@@ -1933,7 +1949,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   T* y_l = x_l + lds_nloc;                                                                         \
   T* x2_l = y_l + lds_nloc; /* second input (NF == 2 only) */                                      \
   T* scratch = x2_l + (NF == 2 ? lds_nloc : 0);                                                    \
-  T* D_l = scratch + (size_t)slots * (Nd + N); /* derivative table (tiles: Nd + N each) */         \
+  T* D_l = scratch + (size_t)slots * SLOT; /* derivative table (tiles: SLOT entries each) */       \
   T* cf_l = D_l + N2; /* per-element coefficient(s) */                                             \
   T* cf2_l = cf_l + lds_nelem;                                                                     \
   T* gc_l = cf2_l + (NF == 2 ? lds_nelem : 0); /* affine: 6 G + 1 detJ; trilinear: 21 map coefficients */ \
@@ -1962,7 +1978,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   const int myslot = (wave * EPW + (active ? s : 0)) * EPS;                                        \
   /* exchange tiles follow x_l, y_l (, x2_l); one per element slot */                              \
   T* sA = reinterpret_cast<T*>(smem_raw) + (size_t)(NF == 2 ? 3 : 2) * q->A.lds_nloc                \
-          + (size_t)myslot * (Nd + N);                                                             \
+          + (size_t)myslot * SLOT;                                                                 \
   T* sB = sA
 
   // A workgroup walks the blocks blk, blk + gridDim.x, ... of the launch's range (a launch with one

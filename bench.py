@@ -156,9 +156,10 @@ class _DevBuf:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
-def torch_exchange(torch, dist, model, rank, loopback=False):
+def torch_exchange(torch, dist, model, rank, loopback=False, host_staged=False):
     """exchange() for the external transport: neighbour ranges of the library's send buffer go to the
-    neighbours' receive buffers with torch.distributed P2P (NCCL = RCCL); loopback: to the own one."""
+    neighbours' receive buffers with torch.distributed P2P (NCCL = RCCL); loopback: to the own one;
+    host_staged (rehearsal of N ranks on fewer devices): device -> pinned host -> gloo -> device."""
     ranks, counts, offs = model.data.halo_layout()
     sp, rp, n = model.data.halo_buffers()
     if n == 0:
@@ -166,10 +167,22 @@ def torch_exchange(torch, dist, model, rank, loopback=False):
     ts = "<f8" if model.data.dtype == np.float64 else "<f4"
     send = torch.as_tensor(_DevBuf(sp, n, ts), device="cuda")
     recv = torch.as_tensor(_DevBuf(rp, n, ts), device="cuda")
+    if host_staged:
+        hs, hr = torch.empty_like(send, device="cpu").pin_memory(), torch.empty_like(recv, device="cpu").pin_memory()
 
     def exchange():
         if loopback:
             recv.copy_(send)
+        elif host_staged:
+            hs.copy_(send)
+            torch.cuda.synchronize()
+            ops = []
+            for q, c, o in zip(ranks.tolist(), counts.tolist(), offs.tolist()):
+                ops.append(dist.P2POp(dist.irecv, hr[o:o + c], q))
+                ops.append(dist.P2POp(dist.isend, hs[o:o + c], q))
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+            recv.copy_(hr)
         else:
             ops = []
             for q, c, o in zip(ranks.tolist(), counts.tolist(), offs.tolist()):
@@ -235,6 +248,48 @@ def live_traffic(argv_tail, P, dtype):
     rd, wr = 2.0 * per["FETCH_SIZE"][0], per["WRITE_SIZE"][0]
     return {"hbm_bytes_per_launch": rd + wr, "read_bytes_per_launch": rd, "write_bytes_per_launch": wr,
             "launches": per["FETCH_SIZE"][1]}, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command"
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launcher_command(n, argv, port):
+    """The rank processes of `bench.py --gpus n` run as a plain command: one torch.distributed.run child (n ranks of
+    this script with the same arguments, rendezvous on 127.0.0.1)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr",
+            "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+
+
+def self_launch(n, argv, ndev, run=subprocess.run):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: this parent never touches the GPU (it only
+    counted the devices); it starts the N ranks as a CHILD process tree (no exec), relays rank 0's single JSON line
+    to its own stdout and returns the children's exit code.  With fewer devices than ranks (a one-GPU box) the
+    ranks run as a rehearsal: they share the devices round-robin and the exchange is staged through host memory
+    over gloo (RCCL refuses two ranks on one device); the JSON line says so (`rehearsal`)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if ndev < n:
+        env["FUSMI_BENCH_REHEARSAL"] = str(ndev)
+        print(f"[bench] {n} ranks on {ndev} device(s): rehearsal (shared devices, host-staged gloo exchange)", file=sys.stderr)
+    cmd = launcher_command(n, argv, _free_port())
+    r = run(cmd, stdout=subprocess.PIPE, env=env, cwd=os.getcwd())
+    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{") and ln.rstrip().endswith("}")]
+    if r.returncode == 0 and not lines:
+        print("[bench] the ranks exited 0 without a result line", file=sys.stderr)
+        return 4
+    if lines:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    else:
+        print(f"[bench] the {n}-rank launch failed (exit code {r.returncode}); command: {' '.join(cmd)}", file=sys.stderr)
+    return r.returncode
+
 
 
 def main():
@@ -307,14 +362,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     launched = "RANK" in os.environ and "MASTER_PORT" in os.environ   # under torch.distributed.run
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
 
     import torch
 
-    if torch.cuda.device_count() == 0:      # (counting devices does not initialise the GPU)
+    ndev = torch.cuda.device_count()        # (counting devices does not initialise the GPU)
+    if ndev == 0:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
+    if world != args.gpus:
+        if not launched and args.gpus > 1:
+            # a plain `python bench.py --gpus N`: start the N ranks ourselves (child processes), relay the line
+            os.dup2(result_fd, 1)
+            os.close(result_fd)
+            sys.exit(self_launch(args.gpus, sys.argv[1:], ndev))
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # N ranks on fewer devices (set by self_launch on a one-GPU box, or by hand): shared devices, gloo, host-staged exchange
+    rehearsal = int(os.environ.get("FUSMI_BENCH_REHEARSAL", "0")) if world > 1 else 0
 
     # ---- live HBM traffic of the dominant kernel (child processes, before this one touches the GPU) ----
     traffic, traffic_src = None, None
@@ -335,8 +397,10 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible")
-    if "FUSMI_BENCH_DEVICE" in os.environ:   # rehearsal of N>1 on a one-GPU box
+    if "FUSMI_BENCH_DEVICE" in os.environ:   # every rank on one named device
         local_rank = int(os.environ["FUSMI_BENCH_DEVICE"])
+    elif rehearsal:
+        local_rank = local_rank % rehearsal
     torch.cuda.set_device(local_rank)
 
     import fenicsxfus_amd as fa
@@ -348,7 +412,7 @@ def main():
                      ("diag_metric", args.diag_metric)):
         if val is not None:
             ctx.set_option(key, val)
-    transport = args.transport
+    transport = "torch" if rehearsal else args.transport
     if args.halo_loopback:
         assert world == 1 and not launched
         if transport == "torch":
@@ -363,7 +427,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         if transport == "rccl":
             # the library's own communicator; a failure here is fatal (exit non-zero, nothing is re-launched)
             try:
@@ -390,7 +457,7 @@ def main():
 
     def max_over_ranks(x):
         if world > 1 or launched:
-            tt = torch.tensor([x], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return float(tt.item())
         return x
@@ -419,7 +486,8 @@ def main():
                                                       4, dt, V=V, ctx=context)
         if transport == "torch" and (world > 1 or args.halo_loopback):
             # external transport: the host drives the two halves of every stage around a torch P2P exchange
-            exch = torch_exchange(torch, dist if world > 1 else None, model, rank, loopback=args.halo_loopback)
+            exch = torch_exchange(torch, dist if world > 1 else None, model, rank, loopback=args.halo_loopback,
+                                  host_staged=bool(rehearsal))
             model.external_setup(exch)
 
             def advance(t, n):
@@ -610,6 +678,17 @@ def main():
                                     "achieved_GBps": st_bytes / (st_ms / 4 * 1e-3) / 1e9,
                                     "frac_of_8TBps": st_bytes / (st_ms / 4 * 1e-3) / 8e12,
                                     "share_of_step": st_ms / (1e3 * elapsed / args.steps)}
+        if world > 1 or args.halo_loopback:
+            # who moved the interface values: the library's own RCCL communicator (ncclSend / ncclRecv between `nranks`
+            # ranks, replacing la::Vector::scatter_fwd / scatter_rev of Linear.hpp:196-206), or torch.distributed
+            out["comm"] = {"transport": transport, "nranks": int(getattr(ctx, "nranks", world)),
+                           "backend": ("gloo, interface values staged through host memory" if rehearsal else
+                                       ("RCCL ncclSend/ncclRecv on the library's comm stream" if transport == "rccl"
+                                        else "torch.distributed P2P (NCCL = RCCL)")),
+                           "devices_visible": int(ndev)}
+        if rehearsal:
+            out["rehearsal"] = (f"{world} ranks shared {rehearsal} device(s); exchange staged through host memory over gloo "
+                                "-- correctness rehearsal of the N>1 path, NOT a scaling measurement")
         if overlap_ab:
             out["exchange_overlap"] = {"what": "ms per step with the exchange hidden behind the shared-dof stage kernel only "
                                                "(off) or also behind the non-interface blocks (on), timed during warm-up",

@@ -25,6 +25,78 @@ def test_bench_refuses_to_run_without_gpu():
     assert out.stdout.strip() == ""            # no result line
 
 
+def test_self_launch_relays_rank0_line_and_exit_code(capsys, monkeypatch):
+    """`python bench.py --gpus N` as a plain command (the driver's SCALE command): the parent starts the ranks as a child
+    torch.distributed.run (never exec), relays rank 0's one JSON line and returns the children's exit code."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    cmd = bench.launcher_command(8, ["--gpus", "8", "--steps", "5"], 29517)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=8" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "5"]
+
+    seen = {}
+
+    class R:
+        def __init__(self, rc, out):
+            self.returncode, self.stdout = rc, out
+
+    def fake_ok(cmd, stdout=None, env=None, cwd=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return R(0, b'RCCL banner\n{"metric": "m", "n_gpus": 8}\n')
+
+    monkeypatch.delenv("FUSMI_BENCH_REHEARSAL", raising=False)
+    assert bench.self_launch(8, ["--gpus", "8"], ndev=8, run=fake_ok) == 0
+    out = capsys.readouterr().out
+    assert out == '{"metric": "m", "n_gpus": 8}\n'               # one line, nothing else
+    assert "FUSMI_BENCH_REHEARSAL" not in seen["env"]
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and seen["env"]["MASTER_ADDR"] == "127.0.0.1"
+    assert seen["cmd"][seen["cmd"].index("--nproc-per-node=8")] and "exec" not in " ".join(seen["cmd"])
+
+    # fewer devices than ranks: the ranks are told to share them (rehearsal)
+    assert bench.self_launch(2, ["--gpus", "2"], ndev=1, run=fake_ok) == 0
+    assert seen["env"]["FUSMI_BENCH_REHEARSAL"] == "1"
+    capsys.readouterr()
+
+    # a failing rank: non-zero exit code, no result line
+    assert bench.self_launch(2, ["--gpus", "2"], ndev=2, run=lambda *a, **k: R(3, b"noise\n")) == 3
+    assert capsys.readouterr().out == ""
+    # ranks that exit 0 without printing a result are an error too
+    assert bench.self_launch(2, ["--gpus", "2"], ndev=2, run=lambda *a, **k: R(0, b"")) != 0
+
+
+def test_bench_gpus_2_without_gpu_fails_cleanly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("device present")
+    out = run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--cells", "4", "--no-cpu")
+    assert out.returncode != 0 and out.stdout.strip() == ""
+    assert "no HIP device" in out.stderr
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_self_launched_on_one_box():
+    """The N > 1 path end to end through `python bench.py --gpus 2` (self-launch): two distinct rank processes, each
+    with its own x-slab, exchanging their interface plane every stage.  On a one-GPU box the two ranks share the
+    device and the exchange is staged over gloo (rehearsal); on a multi-GPU box it is the library's RCCL path."""
+    out = run_bench("--gpus", "2", "--steps", "3", "--warmup", "1", "--repeats", "2", "--cells", "8", "--no-cpu",
+                    "--traffic", "none", timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["finite_nonzero_solution"] is True
+    assert d["comm"]["nranks"] == 2
+    assert d["config"]["ndofs_global"] == (2 * 8 * 4 + 1) * (8 * 4 + 1) ** 2
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert "rehearsal" in d and d["comm"]["transport"] == "torch"
+    else:
+        assert d["comm"]["transport"] == "rccl" and "exchange_overlap" in d
+
+
 @pytest.mark.gpu
 def test_bench_json_contract():
     out = run_bench("--steps", "3", "--warmup", "1", "--repeats", "3", "--cells", "16", "--cpu-n", "8", "--cpu-steps", "5",

@@ -474,3 +474,77 @@ def test_slabs_higher_degree_gpu(orc, Ph):
         mdl.close()
     for cx in ctxs:
         cx.close()
+
+
+def _gpu_rank_worker(rank, size, port, q):
+    """One RANK PROCESS of the N > 1 path on the HIP library: its own x-slab, the library's pack / ordered-sum / stage
+    kernels, interface values moved between the processes by gloo through host memory (the external-transport entry
+    points of fusmi.h; on a multi-GPU node the library's RCCL send/recv takes this place)."""
+    import ctypes
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=size)
+    import torch
+
+    hip = ctypes.CDLL("libamdhip64.so")
+    cx = fa.Context(0)
+    cx.init_external(rank, size)
+    mesh = fa.BoxMesh([0, 0, 0], HI, N_GLOBAL, rank=rank, size=size, perturb=0.1)
+    V = fa.FunctionSpace(mesh, P)
+    c, rho = material(mesh)
+    dt = dt_value()
+    mdl = fa.LinearSpectralExplicit(mesh, fa.tag_box_boundary(mesh), P, c, rho, F0, P0, S0, 4, dt, V=V, ctx=cx)
+    ranks, counts, offs = mdl.data.halo_layout()
+    sp, rp, n = mdl.data.halo_buffers()
+    hs, hr = np.zeros(n), np.zeros(n)
+
+    def exchange():
+        assert hip.hipMemcpy(ctypes.c_void_p(hs.ctypes.data), ctypes.c_void_p(sp), ctypes.c_size_t(8 * n), 2) == 0
+        ops, bufs = [], []
+        for qr, cnt, off in zip(ranks.tolist(), counts.tolist(), offs.tolist()):
+            rb = torch.empty(cnt, dtype=torch.float64)
+            bufs.append((off, cnt, rb))
+            ops.append(dist.P2POp(dist.irecv, rb, qr))
+            ops.append(dist.P2POp(dist.isend, torch.from_numpy(hs[off:off + cnt].copy()), qr))
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+        for off, cnt, rb in bufs:
+            hr[off:off + cnt] = rb.numpy()
+        assert hip.hipMemcpy(ctypes.c_void_p(rp), ctypes.c_void_p(hr.ctypes.data), ctypes.c_size_t(8 * n), 1) == 0
+
+    mdl.external_setup(exchange)
+    mdl.init()
+    mdl.external_rk_steps(0.0, dt, NSTEPS, exchange)
+    q.put((rank, V.global_offset, mdl.mass_vector(), mdl.u_sol().x.array.copy(), mdl.v_n.x.array.copy()))
+    dist.barrier()
+    mdl.close()
+    cx.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [2, 3])
+def test_distinct_rank_processes_gpu(orc, size):
+    """Two / three distinct rank PROCESSES on the HIP path (they share this box's one GPU; gloo moves the interface
+    values): state equal to the single-rank oracle, interface planes bit-identical on both sharers."""
+    import torch.multiprocessing as mp
+
+    ref, m_ref, u_ref, v_ref = single_rank_reference(orc)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gpu_rank_worker, args=(r, size, port, q)) for r in range(size)]
+    [p.start() for p in procs]
+    res = sorted((q.get(timeout=600) for _ in procs), key=lambda t: t[0])
+    [p.join(timeout=120) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    for rank, off, m, u, v in res:
+        k = len(u)
+        assert np.abs(m - m_ref[off:off + k]).max() < 1e-14 * np.abs(m_ref).max()
+        assert np.abs(u - u_ref[off:off + k]).max() < 1e-10 * np.abs(u_ref).max()
+        assert np.abs(v - v_ref[off:off + k]).max() < 1e-10 * np.abs(v_ref).max()
+    for a, b in zip(res[:-1], res[1:]):
+        plane = len(a[3]) - (b[1] - a[1])
+        assert plane > 0 and np.array_equal(a[3][-plane:], b[3][:plane])

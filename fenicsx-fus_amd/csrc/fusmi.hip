@@ -270,6 +270,14 @@ struct fus_model
   // k_boundary_partial only when they are not (first stage after init / set, other RK orders).
   bool bnd_valid = false;
   double bnd_tn = 0.0;
+  // receivers (fus_model_set_receivers): per point the internal indices of its cell's dofs and the 1-D basis
+  // values at its reference coordinates; record buffer for sampling every k steps inside the RK loops
+  int64_t rc_n = 0;
+  int32_t* d_rc_idx = nullptr;
+  void *d_rc_bas = nullptr, *d_rc_out = nullptr, *d_rec = nullptr;
+  int rec_every = 0, rec_which = 0;
+  int64_t rec_cap = 0, rec_n = 0, rec_step = 0;
+  std::vector<double> rec_times;
 };
 
 // -------------------------------------------------------------------------------------------------
@@ -2679,6 +2687,154 @@ int fus_model_init(fus_model* m)
   return FUS_OK;
 }
 
+// ---- receivers: point samples of the resident solution (reference: Function::eval at located cells,
+// python/src/fenicsxfus/utils.py:10-47, cpp/mwe/parallel_eval_line/main.cpp:49-84) ----
+static void launch_sample(fus_model* m, int which, void* out)
+{
+  fus_op* op = m->op;
+  const void* vec = which == FUS_U ? m->u0 : m->v0;
+  const dim3 grid((unsigned)((m->rc_n + 3) / 4)), blockd(256);
+  hipStream_t st = m->ctx->stream;
+#define FUS_SAMPLE(T, TD)                                                                          \
+  hipLaunchKernelGGL((k_sample<T, TD>), grid, blockd, 0, st, m->rc_n, op->N, m->d_rc_idx,          \
+                     static_cast<const T*>(m->d_rc_bas), static_cast<const T*>(vec), static_cast<T*>(out))
+  if (op->dtype == FUS_F64)
+  {
+    if (op->tdim == 3)
+      FUS_SAMPLE(double, 3);
+    else
+      FUS_SAMPLE(double, 2);
+  }
+  else
+  {
+    if (op->tdim == 3)
+      FUS_SAMPLE(float, 3);
+    else
+      FUS_SAMPLE(float, 2);
+  }
+#undef FUS_SAMPLE
+}
+
+// after a step that ended at time t: every rec_every-th step, one sample of the receivers into the record buffer
+static int model_record_step(fus_model* m, double t)
+{
+  if (m->rec_every <= 0)
+    return FUS_OK;
+  ++m->rec_step;
+  if (m->rec_step % m->rec_every != 0 || m->rec_n >= m->rec_cap)
+    return FUS_OK;
+  launch_sample(m, m->rec_which, static_cast<char*>(m->d_rec) + (size_t)m->rec_n * m->rc_n * m->op->ts);
+  HIPCHK(hipGetLastError());
+  m->rec_times.push_back(t);
+  ++m->rec_n;
+  return FUS_OK;
+}
+
+int fus_model_set_receivers(fus_model* m, int64_t npts, const int32_t* cells, const double* refcoords)
+{
+  if (!m || npts < 0 || (npts > 0 && (!cells || !refcoords)))
+    return fail(FUS_ERR_ARG, "bad argument");
+  fus_op* op = m->op;
+  HIPCHK(hipSetDevice(m->ctx->device));
+  const int N = op->N, Nd = op->Nd, td = op->tdim;
+  for (int64_t r = 0; r < npts; ++r)
+    if (cells[r] < 0 || cells[r] >= op->ncells)
+      return fail(FUS_ERR_ARG, "receiver cell index out of range (points outside the local mesh must be dropped by the caller)");
+  // internal indices of each receiver's cell dofs; 1-D Lagrange basis on the operator's nodes at the reference coordinates
+  std::vector<int32_t> idx((size_t)npts * Nd);
+  std::vector<double> bas((size_t)npts * td * N);
+  for (int64_t r = 0; r < npts; ++r)
+  {
+    const int32_t* dm = op->h_dofmap.data() + (size_t)cells[r] * Nd;
+    for (int k = 0; k < Nd; ++k)
+      idx[(size_t)r * Nd + k] = op->L.dof_perm[dm[k]];
+    for (int d = 0; d < td; ++d)
+    {
+      const double X = refcoords[r * td + d];
+      for (int i = 0; i < N; ++i)
+      {
+        double l = 1.0;
+        for (int j = 0; j < N; ++j)
+          if (j != i)
+            l *= (X - op->nodes[j]) / (op->nodes[i] - op->nodes[j]);
+        bas[((size_t)r * td + d) * N + i] = l;
+      }
+    }
+  }
+  hipStream_t st = m->ctx->stream;
+  HIPCHK(hipStreamSynchronize(st));
+  m->rc_n = npts;
+  m->rec_every = 0, m->rec_n = 0, m->rec_cap = 0, m->rec_times.clear();
+  FUSCHK(upload(m->allocs, &m->d_rc_idx, idx, st));
+  if (op->dtype == FUS_F64)
+  {
+    double* q = nullptr;
+    FUSCHK(upload(m->allocs, &q, bas, st));
+    m->d_rc_bas = q;
+  }
+  else
+  {
+    std::vector<float> bf(bas.begin(), bas.end());
+    float* q = nullptr;
+    FUSCHK(upload(m->allocs, &q, bf, st));
+    m->d_rc_bas = q;
+    HIPCHK(hipStreamSynchronize(st));  // bf leaves scope
+  }
+  FUSCHK(dalloc_bytes(m->allocs, &m->d_rc_out, (size_t)npts * op->ts, true, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return FUS_OK;
+}
+
+int fus_model_sample(fus_model* m, int which, void* out, int space)
+{
+  if (!m || !out || (which != FUS_U && which != FUS_V))
+    return fail(FUS_ERR_ARG, "bad argument");
+  if (m->rc_n == 0)
+    return m->d_rc_idx ? FUS_OK : fail(FUS_ERR_STATE, "fus_model_set_receivers has not been called");
+  HIPCHK(hipSetDevice(m->ctx->device));
+  hipStream_t st = m->ctx->stream;
+  launch_sample(m, which, space == FUS_HOST ? m->d_rc_out : out);
+  HIPCHK(hipGetLastError());
+  if (space == FUS_HOST)
+    HIPCHK(hipMemcpyAsync(out, m->d_rc_out, (size_t)m->rc_n * m->op->ts, hipMemcpyDeviceToHost, st));
+  HIPCHK(hipStreamSynchronize(st));
+  return FUS_OK;
+}
+
+int fus_model_record(fus_model* m, int which, int every, int64_t capacity)
+{
+  if (!m || (which != FUS_U && which != FUS_V) || every < 0 || capacity < 0)
+    return fail(FUS_ERR_ARG, "bad argument");
+  if (every > 0 && !m->d_rc_idx)
+    return fail(FUS_ERR_STATE, "fus_model_set_receivers has not been called");
+  HIPCHK(hipSetDevice(m->ctx->device));
+  m->rec_every = every, m->rec_which = which, m->rec_n = 0, m->rec_step = 0, m->rec_times.clear();
+  if (every > 0 && capacity > m->rec_cap)
+  {
+    FUSCHK(dalloc_bytes(m->allocs, &m->d_rec, (size_t)capacity * std::max<int64_t>(m->rc_n, 1) * m->op->ts, false, m->ctx->stream));
+    m->rec_cap = capacity;
+  }
+  return FUS_OK;
+}
+
+int fus_model_get_records(fus_model* m, void* out, double* times, int64_t* nrec)
+{
+  if (!m || !nrec)
+    return fail(FUS_ERR_ARG, "bad argument");
+  HIPCHK(hipSetDevice(m->ctx->device));
+  const int64_t n = m->rec_n;
+  if (out && n > 0 && m->rc_n > 0)
+  {
+    HIPCHK(hipMemcpyAsync(out, m->d_rec, (size_t)n * m->rc_n * m->op->ts, hipMemcpyDeviceToHost, m->ctx->stream));
+    HIPCHK(hipStreamSynchronize(m->ctx->stream));
+  }
+  if (times)
+    for (int64_t k = 0; k < n; ++k)
+      times[k] = m->rec_times[k];
+  *nrec = n;
+  return FUS_OK;
+}
+
 int fus_model_rk4(fus_model* m, double t0, double tf_, double dt_, int64_t* nsteps)
 {
   if (!m)
@@ -2700,6 +2856,7 @@ int fus_model_rk4(fus_model* m, double t0, double tf_, double dt_, int64_t* nste
       FUSCHK(d_model_step(m, t, dt));
       t += dt;
       ++step;
+      FUSCHK(model_record_step(m, t));
     }
   }
   else
@@ -2711,6 +2868,7 @@ int fus_model_rk4(fus_model* m, double t0, double tf_, double dt_, int64_t* nste
       FUSCHK(d_model_step(m, t, dt));
       t += dt;
       ++step;
+      FUSCHK(model_record_step(m, t));
     }
   }
   HIPCHK(hipStreamSynchronize(m->ctx->stream));
@@ -2733,6 +2891,7 @@ int fus_model_rk4_steps(fus_model* m, double t0, double dt, int64_t nsteps)
   {
     FUSCHK(d_model_step(m, t, dt));
     t += dt;
+    FUSCHK(model_record_step(m, t));
   }
   return FUS_OK;
 }

@@ -3051,6 +3051,47 @@ __global__ void __launch_bounds__(256) k_stream_copy(int64_t nvec, const V* __re
 
 // halo helpers
 // pack: sendbuf[k] = vec[idx[k]] over the concatenated neighbour lists
+// Receiver sampling (the reference evaluates its solution at points with Function::eval after locating their cells:
+// python/src/fenicsxfus/utils.py:10-47, cpp/mwe/parallel_eval_line/main.cpp:49-84).  One wave per receiver r:
+//   out[r] = sum_{i0,i1,i2} l_i0(X0) l_i1(X1) l_i2(X2) vec[idx[r][i0,i1,i2]]
+// on the RESIDENT vector in internal numbering (idx = dof_perm of the receiver's cell dofs, bas = the 1-D Lagrange
+// basis values at the receiver's reference coordinates, both built once in fus_model_set_receivers); lane k adds
+// the entries k, k + 64, ... in that order, then a fixed butterfly: the same bits on every call.
+template <typename T, int TD>
+__global__ void __launch_bounds__(256)
+k_sample(int64_t npts, int N, const int32_t* __restrict__ idx, const T* __restrict__ bas,
+         const T* __restrict__ vec, T* __restrict__ out)
+{
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + wave;
+  if (r >= npts)
+    return;  // (the whole wave leaves)
+  const int N2 = N * N, Nd = (TD == 3) ? N2 * N : N2;
+  const int32_t* __restrict__ ix = idx + r * Nd;
+  const T* __restrict__ b = bas + r * (TD * N);
+  T acc = T(0);
+  for (int k = lane; k < Nd; k += 64)
+  {
+    T w;
+    if (TD == 3)
+    {
+      const int i0 = k / N2, rem = k - i0 * N2, i1 = rem / N, i2 = rem - i1 * N;
+      w = b[i0] * b[N + i1] * b[2 * N + i2];
+    }
+    else
+    {
+      const int i0 = k / N, i1 = k - i0 * N;
+      w = b[i0] * b[N + i1];
+    }
+    acc += w * vec[ix[k]];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+    acc += __shfl_xor(acc, o, 64);
+  if (lane == 0)
+    out[r] = acc;
+}
+
 template <typename T>
 __global__ void k_pack(int64_t n, const int32_t* __restrict__ idx, const T* __restrict__ vec,
                        T* __restrict__ buf)

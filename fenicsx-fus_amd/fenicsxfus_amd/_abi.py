@@ -26,6 +26,7 @@ SYMBOLS = [
     "fus_group_finish_setup", "fus_group_rk4_steps", "fus_op_halo_layout", "fus_op_halo_buffers",
     "fus_model_setup_count", "fus_model_setup_pack", "fus_model_setup_unpack", "fus_model_setup_finish",
     "fus_model_stage_begin", "fus_model_stage_end",
+    "fus_model_set_receivers", "fus_model_sample", "fus_model_record", "fus_model_get_records",
 ]
 
 

@@ -53,6 +53,7 @@ class _SpectralExplicit:
         check(lib().fus_model_set_rk_order(self.h, C.c_int(rk_order)))
         self.u_n = Function(self.V, dt_)
         self.v_n = Function(self.V, dt_)
+        self._nrecv = 0
 
     # ---- external transport (the caller exchanges the interface values; fusmi.h) ----
     def setup_count(self) -> int:
@@ -127,6 +128,41 @@ class _SpectralExplicit:
                 exchange()
                 self.stage_end(i, t, dt)
             t += dt
+
+    # ---- receivers: point samples of the resident solution (utils.py:10-47 compute_eval_params + Function.eval) ----
+    def set_receivers(self, points):
+        """Locate ``points`` [n, tdim|3] in the local mesh (host, once) and hand (cell, reference coordinates) to the
+        library; returns the indices of the points found on this rank (the reference's ``points_on_proc``)."""
+        from .evaluate import locate
+
+        cell, X = locate(self.mesh, points)
+        on = np.flatnonzero(cell >= 0)
+        cells = np.ascontiguousarray(cell[on], dtype=np.int32)
+        Xr = np.ascontiguousarray(X[on], dtype=np.float64)
+        check(lib().fus_model_set_receivers(self.h, C.c_int64(len(on)), ptr(cells), ptr(Xr)))
+        self._nrecv = len(on)
+        return on
+
+    def sample(self, which: str = "u"):
+        """u_h (or v_h) at the receivers, evaluated on the device from the resident vector."""
+        out = np.zeros(self._nrecv, dtype=self.data.dtype)
+        w = _abi.FUS_U if which == "u" else _abi.FUS_V
+        check(lib().fus_model_sample(self.h, C.c_int(w), ptr(out), C.c_int(_abi.FUS_HOST)))
+        return out
+
+    def record(self, every: int, capacity: int, which: str = "u"):
+        """Sample the receivers after every ``every``-th step of rk() / rk4_steps() into a device buffer."""
+        w = _abi.FUS_U if which == "u" else _abi.FUS_V
+        check(lib().fus_model_record(self.h, C.c_int(w), C.c_int(every), C.c_int64(capacity)))
+
+    def records(self):
+        """(times [nrec], samples [nrec, npts]) recorded so far."""
+        n = C.c_int64()
+        check(lib().fus_model_get_records(self.h, None, None, C.byref(n)))
+        out = np.zeros((n.value, self._nrecv), dtype=self.data.dtype)
+        times = np.zeros(n.value)
+        check(lib().fus_model_get_records(self.h, ptr(out), ptr(times), C.byref(n)))
+        return times, out
 
     def u_sol(self):
         self._pull()

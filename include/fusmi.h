@@ -253,6 +253,24 @@ int fus_model_set(fus_model* model, int which, const void* in, int space);
 int fus_model_get_mass(fus_model* model, void* out);
 int64_t fus_model_ndofs(fus_model* model); /* number_of_dofs(), Linear.hpp:318 (local) */
 
+/* ---- receivers: point samples of the resident solution ------------------------------------------
+ * Replaces Function::eval(points, cells) after the cell search of compute_eval_params
+ * (python/src/fenicsxfus/utils.py:10-47) / geometry::compute_colliding_cells
+ * (cpp/mwe/parallel_eval_line/main.cpp:49-84): the caller locates each point (cell = local cell index in caller
+ * numbering, refcoords = its reference coordinates in [0,1]^tdim, double[npts*tdim], X0 pairing with tensor index
+ * 0 of the dofmap) and drops points outside the local mesh, as the reference does (points_on_proc).  The library
+ * keeps, per receiver, the internal indices of its cell's dofs and the 1-D Lagrange basis values, and evaluates
+ * u_h (FUS_U) or v_h (FUS_V) at the receivers from the vectors resident in HBM -- no full-vector copy.
+ *   fus_model_sample       T[npts] now, into host or device memory (`space`)
+ *   fus_model_record       sample `which` after every `every`-th step of fus_model_rk4 / fus_model_rk4_steps into a
+ *                          device buffer of `capacity` records (every = 0: off); restarts the record count
+ *   fus_model_get_records  copies the records taken so far (T[nrec*npts], row = record) and their times; out / times
+ *                          may be NULL to query *nrec only */
+int fus_model_set_receivers(fus_model* model, int64_t npts, const int32_t* cells, const double* refcoords);
+int fus_model_sample(fus_model* model, int which, void* out, int space);
+int fus_model_record(fus_model* model, int which, int every, int64_t capacity);
+int fus_model_get_records(fus_model* model, void* out, double* times, int64_t* nrec);
+
 int fus_group_finish_setup(fus_model** models, int n);
 int fus_group_rk4_steps(fus_model** models, int n, double t0, double dt, int64_t nsteps);
 

@@ -232,6 +232,32 @@ public:
     return m;
   }
   std::int64_t number_of_dofs() const { return fus_model_ndofs(h_); }  // Linear.hpp:318
+  // receivers: u->eval(points_on_proc, shape, cells, u_eval, ...) of cpp/mwe/parallel_eval_line/main.cpp:49-84 on the
+  // resident solution -- cells / reference coordinates located by the caller (points outside the rank dropped)
+  void set_receivers(const std::vector<std::int32_t>& cells, const std::vector<double>& refcoords)
+  {
+    nrecv_ = (std::int64_t)cells.size();
+    check(fus_model_set_receivers(h_, nrecv_, cells.data(), refcoords.data()));
+  }
+  std::vector<T> eval(int which = FUS_U) const
+  {
+    std::vector<T> out((size_t)nrecv_);
+    check(fus_model_sample(h_, which, out.data(), FUS_HOST));
+    return out;
+  }
+  // sample after every `every`-th step of rk4 / rk4_steps into a device buffer of `capacity` records
+  void record(int every, std::int64_t capacity, int which = FUS_U) { check(fus_model_record(h_, which, every, capacity)); }
+  std::vector<T> records(std::vector<double>* times = nullptr) const
+  {
+    std::int64_t n = 0;
+    check(fus_model_get_records(h_, nullptr, nullptr, &n));
+    std::vector<T> out((size_t)(n * nrecv_));
+    std::vector<double> t((size_t)n);
+    check(fus_model_get_records(h_, out.data(), t.data(), &n));
+    if (times)
+      *times = t;
+    return out;
+  }
   fus_model* handle() const { return h_; }
   ~SpectralModel() { fus_model_destroy(h_); }
   SpectralModel(const SpectralModel&) = delete;
@@ -255,6 +281,7 @@ private:
   }
   std::shared_ptr<SpectralOperatorData<T, P>> d_;
   fus_model* h_ = nullptr;
+  std::int64_t nrecv_ = 0;
 };
 } // namespace detail
 

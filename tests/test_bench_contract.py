@@ -90,8 +90,7 @@ def test_bench_two_ranks_self_launched_on_one_box():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["finite_nonzero_solution"] is True
     assert d["comm"]["nranks"] == 2
     assert d["config"]["ndofs_global"] == (2 * 8 * 4 + 1) * (8 * 4 + 1) ** 2
-    import torch
-    if torch.cuda.device_count() < 2:
+    if d["comm"]["devices_visible"] < 2:
         assert "rehearsal" in d and d["comm"]["transport"] == "torch"
     else:
         assert d["comm"]["transport"] == "rccl" and "exchange_overlap" in d

@@ -529,7 +529,9 @@ def _gpu_rank_worker(rank, size, port, q):
 def test_distinct_rank_processes_gpu(orc, size):
     """Two / three distinct rank PROCESSES on the HIP path (they share this box's one GPU; gloo moves the interface
     values): state equal to the single-rank oracle, interface planes bit-identical on both sharers."""
-    import torch.multiprocessing as mp
+    # (no torch in THIS process: it holds the HIP runtime through libfusmi already; the rank processes are fresh
+    # interpreters that import torch first)
+    import multiprocessing as mp
 
     ref, m_ref, u_ref, v_ref = single_rank_reference(orc)
     ctx = mp.get_context("spawn")

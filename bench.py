@@ -91,11 +91,12 @@ def workload(args, rank, size, dtype=np.float64, n_override=None):
         L = 0.12 * g / 64.0
         mesh = fa.BoxMesh([0, 0, 0], [L, L, L], (g, g, g), rank=rank, size=size, dtype=dtype)
         h, Lx = L / g, L
-    else:                                               # weak scaling: n^3 cells per rank
+    else:                                               # weak scaling: n^3 (or nx x ny x nz) cells per rank
         n = n_override or args.cells
-        L1 = 0.12 * n / 64.0
-        mesh = fa.BoxMesh([0, 0, 0], [L1 * size, L1, L1], (n * size, n, n), rank=rank, size=size, dtype=dtype)
-        h, Lx = L1 / n, L1 * size
+        nx, ny, nz = (n, n, n) if (n_override or not args.cells_xyz) else args.cells_xyz
+        h = 0.12 / 64.0
+        mesh = fa.BoxMesh([0, 0, 0], [h * nx * size, h * ny, h * nz], (nx * size, ny, nz), rank=rank, size=size, dtype=dtype)
+        Lx = h * nx * size
     V = fa.FunctionSpace(mesh, P)
     tags = fa.tag_box_boundary(mesh)
     c, rho = medium(args.medium, mesh, Lx)
@@ -333,6 +334,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--repeats", type=int, default=5, help="the timed K-step block is run this many times; value = median")
     ap.add_argument("--cells", type=int, default=64, help="cells per axis per GPU (weak scaling)")
+    ap.add_argument("--cells-xyz", type=int, nargs=3, default=None, metavar=("NX", "NY", "NZ"),
+                    help="cells per GPU as a box NX x NY x NZ instead of --cells^3 (32 256 256 = one rank's x-slab of the "
+                         "256^3 configs[3] / [4] at 8 GPUs, run as a box of its own)")
     ap.add_argument("--global-cells", type=int, default=0,
                     help="strong scaling: a fixed G^3 box cut into N x-slabs (BASELINE configs[3], [4]: 256)")
     ap.add_argument("--medium", choices=["water", "skull", "layers"], default="water",
@@ -420,6 +424,8 @@ def main():
                 "--medium", args.medium]
         if args.global_cells:
             tail += ["--global-cells", str(args.global_cells)]
+        if args.cells_xyz:
+            tail += ["--cells-xyz", *[str(k) for k in args.cells_xyz]]
         for k, v in (("--block-elems", args.block_elems), ("--waves", args.waves), ("--deterministic", args.deterministic),
                      ("--mfma", args.mfma), ("--lean-rk4", args.lean_rk4), ("--walk", args.walk), ("--pack32", args.pack32),
                      ("--diag-metric", args.diag_metric)):
@@ -653,14 +659,22 @@ def main():
         comp_blk, comp_sh, comp_det = compulsory_bytes(info, nc, N3, s, affine, args.model, lean)
         comp_step = 4.0 * (comp_blk + comp_sh) / ndl            # bytes per DOF-update (4 stages)
         copy_bw = ctx.measure_bandwidth()     # measured streaming bandwidth of this device
+        cellsdesc = "x".join(str(k) for k in args.cells_xyz) if args.cells_xyz else f"{args.cells}^3"
         mode = (f"strong scaling: {args.global_cells}^3 box in {world} x-slab(s)" if args.global_cells else
-                f"weak scaling: {args.cells}^3 cells per GPU")
+                f"weak scaling: {cellsdesc} cells per GPU")
         cfgname = {(64, 0, 4, "f64", "water"): "BASELINE.json configs[1]", (128, 0, 7, "f64", "water"): "BASELINE.json configs[2]"}.get(
             (args.cells, args.global_cells, P, args.dtype, args.medium))
         if args.global_cells == 256 and P == 4 and args.dtype == "f64" and args.medium != "water":
             cfgname = "BASELINE.json configs[3]"
         if args.global_cells == 256 and P == 6 and args.dtype == "f32":
             cfgname = "BASELINE.json configs[4]"
+        if args.cells_xyz:
+            cfgname = None
+            if tuple(args.cells_xyz) == (32, 256, 256) and world == 1:
+                if P == 6 and args.dtype == "f32":
+                    cfgname = "one rank's 32x256x256 x-slab of BASELINE.json configs[4] (256^3 over 8 GPUs) as a box of its own"
+                if P == 4 and args.dtype == "f64":
+                    cfgname = "one rank's 32x256x256 x-slab of BASELINE.json configs[3] (256^3 over 8 GPUs) as a box of its own"
         ms_rep = [1e3 * t / args.steps for t in times]
         out = {
             "metric": ("DOF-updates/sec (RK4 step) at p=4 hex fp64" if (P == 4 and args.dtype == "f64") else
@@ -684,7 +698,11 @@ def main():
                        "partition": "middle x-slab of 3, exchange looped back (diagnostic)" if args.halo_loopback
                        else f"x-slabs x{world}", "transport": transport if (world > 1 or args.halo_loopback) else "none",
                        "blocks": info["nblocks"], "mfma_contractions": mfma_used, "packed_fp32": bool(info.get("pack32")),
-                       "lds_bytes_per_block": info["lds_bytes"], "dt": dt},
+                       "lds_bytes_per_block": info["lds_bytes"], "dt": dt,
+                       **({"n1_note": "BASELINE configs[4] on ONE GPU would be 3 630 961 153 local DOFs, beyond the int32 local "
+                                      "indices of the reference's dofmap (and of this library): its smallest run is N = 2; "
+                                      "per-GPU-size lines use --cells-xyz 32 256 256"}
+                          if (P == 6 and args.dtype == "f32" and (args.cells_xyz or args.global_cells)) else {})},
             # the timed K-step block repeated: value / ms_per_step are the median repeat
             "repeats": {"n": len(times), "ms_per_step": ms_rep, "min": min(ms_rep), "max": max(ms_rep),
                         "median": 1e3 * elapsed / args.steps,
@@ -763,7 +781,7 @@ def main():
                         "finite_nonzero_solution": fin2,
                         "options": {"mfma": bool(info2.get("mfma")), "pack32": bool(info2.get("pack32")),
                                     "diag_metric": bool(info2.get("diag_metric"))}}
-        if not args.no_cpu and args.dtype == "f64" and world == 1 and not args.global_cells:   # CPU leg on rank 0 at N=1 only
+        if not args.no_cpu and args.dtype == "f64" and world == 1 and not args.global_cells and not args.cells_xyz:   # CPU leg on rank 0 at N=1 only
             nd_cpu = (args.cpu_n * P + 1) ** 3
             out["cpu_baseline"] = cpu_baseline(args, args.cpu_n, args.cpu_steps or max(4, int(15 * 9e7 / nd_cpu)))
         os.write(result_fd, (json.dumps(out) + "\n").encode())

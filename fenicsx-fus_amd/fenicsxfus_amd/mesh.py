@@ -224,14 +224,21 @@ class FunctionSpace:
         self.dof_grid, self.dof_grid_global = nd, ndg
         ci = mesh._cidx
         loc = np.indices((N,) * t).reshape(t, -1)
-        dm = np.zeros((ci.shape[1], N**t), dtype=np.int64)
-        for d in range(t):
-            dm = dm * nd[d] + (ci[d][:, None] * P + order[loc[d]][None, :])
         ndofs = int(np.prod(nd))
+        assert ndofs < 2**31, "local DOF indices are int32 (as in the reference's dofmap)"
+        # dof(cell, local) = base(cell) + offset(local): the lexicographic index is linear in both parts, so the
+        # [ncells, N^t] table is one int32 broadcast add (a 256^3 p=4 box is 8.4 GB of dofmap; no int64 temporaries)
+        base = np.zeros(ci.shape[1], dtype=np.int64)
+        off = np.zeros(N**t, dtype=np.int64)
+        for d in range(t):
+            base = base * nd[d] + ci[d] * P
+            off = off * nd[d] + order[loc[d]]
+        dm = np.empty((ci.shape[1], N**t), dtype=np.int32)
+        np.add(base.astype(np.int32)[:, None], off.astype(np.int32)[None, :], out=dm)
         plane = int(np.prod(nd[1:]))
         self.plane = plane
         self.global_offset = mesh.cx0 * P * plane  # local dof l  <->  global dof l + offset
-        self.dofmap = _DofMap(dm.astype(np.int32), _IndexMap(ndofs, 0, int(np.prod(ndg))))
+        self.dofmap = _DofMap(dm, _IndexMap(ndofs, 0, int(np.prod(ndg))))
         self.tensor_dofmap = self.dofmap.list
         # shared interface planes with the slab neighbours: (neighbour rank, local dof indices),
         # both sides list the plane in the same (global id) order

@@ -113,10 +113,10 @@ def test_recording_during_rk4_matches_oracle(orc):
     mdl.rk4_steps(0.0, dt, 6)
     times, rec = mdl.records()
     assert rec.shape == (3, 50) and np.allclose(times, [2 * dt, 4 * dt, 6 * dt], rtol=1e-12)
-    # oracle: three runs of 2, 4, 6 steps from rest (the oracle's loop takes floor steps like Linear.hpp:270)
+    # oracle: three runs of 2, 4, 6 steps from rest (+ a ~1e-12 dt remainder step: `while (t < tf)`, Linear.hpp:270)
     for k, ns in enumerate((2, 4, 6)):
         u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
-        orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, F0, P0, S0, 0.0, ns * dt * (1 - 1e-9), dt, u, v)
+        orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, F0, P0, S0, 0.0, ns * dt * (1 + 1e-12), dt, u, v)
         ref = evaluate(pr.V, u, line)
         assert np.abs(u).max() > 0
         assert np.abs(rec[k] - ref).max() < 1e-10 * np.abs(u).max()

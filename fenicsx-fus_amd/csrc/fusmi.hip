@@ -17,6 +17,8 @@
 #include <cstring>
 #include <atomic>
 #include <map>
+#include <mutex>
+#include <tuple>
 #include <memory>
 #include <string>
 #include <vector>
@@ -394,17 +396,25 @@ static int launch_block_op_v(fus_op* op, const T* geo, const T* coef, const T* x
     int per_cu = op->ctx->walk;
     if (per_cu < 0)  // as many workgroups per CU as are resident at once, where each then has >= 4 blocks to walk
     {
-      static int occ[2] = {-1, -1};  // per instantiation; [0]: this LDS size
-      static size_t occ_lds = 0;
-      if (occ[0] < 0 || occ_lds != op->lds_bytes)
+      // resident workgroups per CU of this instantiation, per (device, waves per workgroup, LDS bytes)
+      static std::mutex occ_mu;
+      static std::map<std::tuple<int, int, size_t>, int> occ_cache;
+      int occ = 0;
       {
-        int nb = 0;
-        HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-            &nb, reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD, MF, PK>), 64 * op->L.waves,
-            op->lds_bytes));
-        occ[0] = std::max(nb, 1), occ_lds = op->lds_bytes;
+        std::lock_guard<std::mutex> lk(occ_mu);
+        const auto key = std::make_tuple(op->ctx->device, op->L.waves, op->lds_bytes);
+        auto it = occ_cache.find(key);
+        if (it == occ_cache.end())
+        {
+          int nb = 0;
+          HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+              &nb, reinterpret_cast<const void*>(&k_block_op<T, P, OP, ATOMIC, STAGE, NF, GEOM, TD, MF, PK>), 64 * op->L.waves,
+              op->lds_bytes));
+          it = occ_cache.emplace(key, std::max(nb, 1)).first;
+        }
+        occ = it->second;
       }
-      per_cu = (blk_count >= 4 * occ[0] * op->ctx->num_cus) ? occ[0] : 0;
+      per_cu = (blk_count >= 4 * occ * op->ctx->num_cus) ? occ : 0;
     }
     if (per_cu > 0)
       grid = std::min(blk_count, per_cu * op->ctx->num_cus);

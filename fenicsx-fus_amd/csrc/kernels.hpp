@@ -2275,7 +2275,21 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
       return (r * slots + myslot < sh.nelem) ? r * slots + myslot : -1;
     return (int)rt_l[r * slots + myslot];
   };
+#ifdef FUS_PROBE_PFREE
+  // developer probe (wrong results): a walked block's prologue costs nothing but clearing the accumulator -- the
+  // upper bound of any scheme that has the next block's data in LDS before its trips start (LDS-DMA staging)
+  if (first)
+    p_commit(qc, M, L, true);
+  else
+  {
+    FUS_TID();
+    typedef T V2z __attribute__((ext_vector_type(2)));
+    for (int i = tid; i < (M.sh.nloc + 1) / 2; i += nthr)
+      reinterpret_cast<V2z*>(y_l)[i] = V2z(T(0));
+  }
+#else
   p_commit(qc, M, L, first);
+#endif
   // the next block of this workgroup: its shared-dof indices are requested now and ride through the trips
   // (degrees <= 4: a few registers), so that all of its prologue loads are independent in phase 2
   const int blk_next = blk + blk_stride;
@@ -2408,9 +2422,15 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
     Meta Mn{};
     if (has_next)
       Mn = meta_of(qn, blk_next);
+#ifdef FUS_PROBE_PFREE
+    if constexpr (!IDX_EARLY)
+      p_idx(qn, Mn, false, gi_n);
+    p_load(qn, Mn, L, false, false, gi_n);
+#else
     if constexpr (!IDX_EARLY)
       p_idx(qn, Mn, has_next, gi_n);
     p_load(qn, Mn, L, false, has_next, gi_n);
+#endif
   }
   {
   // this block's epilogue operands (arguments, LDS carve and block data re-derived: see FUS_KARGS)
@@ -2480,8 +2500,13 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
       E.on = i < nvec;
       E.i = i, E.o = int_off + 2 * i;
       E.bv = E.mi = E.w = E.a0 = E.b0 = E.au = E.av = E.m1 = E.m0v = E.us = V2(T(0));
+#ifdef FUS_PROBE_EFREE
+      // developer probe (wrong results): the stage update's operands cost no memory round trip
+      auto ld = [&](const T* ptr) -> V2 { return E.on ? V2(T(1)) + V2(T((uintptr_t)ptr & 7)) : V2(T(0)); };
+#else
       auto ld = [&](const T* ptr) -> V2
       { return E.on ? __builtin_nontemporal_load(reinterpret_cast<const V2*>(ptr + E.o)) : V2(T(0)); };
+#endif
       auto lds = [&](const T* l) -> V2 { return E.on ? reinterpret_cast<const V2*>(l)[i] : V2(T(0)); };
       E.bv = lds(y_l);
       constexpr bool WV = NF == 2;   // Westervelt operands possible (S.mn1 decides at run time)

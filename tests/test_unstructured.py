@@ -454,3 +454,36 @@ def test_hexahedron_27_mesh_on_gpu(orc, tmp_path):
     assert np.abs(d.mass(x, coef, np.zeros(V.num_dofs)) - refm).max() < 1e-13 * np.abs(refm).max()
     d.close()
     ctx.close()
+
+
+def test_hexahedron_27_hand_written_vtk_cell(tmp_path):
+    """One unit-cube Hexahedron_27 cell whose 27 nodes are written out BY HAND in VTK order (vtkTriQuadraticHexahedron:
+    corners 0-3 counter-clockwise on z = 0, 4-7 above them; mid-edge nodes 8-11 bottom ring, 12-15 top ring, 16-19
+    the vertical edges 0-4, 1-5, 2-6, 3-7; face centres 20 x-, 21 x+, 22 y-, 23 y+, 24 z-, 25 z+; 26 body centre) --
+    independent of VTK_HEX27_TO_TENSOR and of the writer used by the other tests.  After reading, node n = nx + 3 ny +
+    9 nz of the cell must sit at (nx, ny, nz) / 2."""
+    from fenicsxfus_amd.unstructured import read_xdmf_mesh
+    vtk_xyz = [
+        (0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1),          # 0-7
+        (.5, 0, 0), (1, .5, 0), (.5, 1, 0), (0, .5, 0),                                                  # 8-11
+        (.5, 0, 1), (1, .5, 1), (.5, 1, 1), (0, .5, 1),                                                  # 12-15
+        (0, 0, .5), (1, 0, .5), (1, 1, .5), (0, 1, .5),                                                  # 16-19
+        (0, .5, .5), (1, .5, .5), (.5, 0, .5), (.5, 1, .5), (.5, .5, 0), (.5, .5, 1),                    # 20-25
+        (.5, .5, .5)]                                                                                    # 26
+    # scramble the point numbering so that the cell's connectivity is not the identity
+    ids = [13, 4, 22, 9, 0, 17, 26, 5, 11, 20, 2, 15, 24, 7, 18, 1, 10, 21, 3, 14, 25, 8, 19, 6, 16, 23, 12]
+    pts = [None] * 27
+    for k, pid in enumerate(ids):
+        pts[pid] = vtk_xyz[k]
+    xml = ('<?xml version="1.0"?><Xdmf Version="3.0"><Domain><Grid Name="mesh" GridType="Uniform">'
+           '<Topology TopologyType="Hexahedron_27" NumberOfElements="1" NodesPerElement="27">'
+           '<DataItem Dimensions="1 27" NumberType="Int" Format="XML">' + " ".join(str(i) for i in ids) + "</DataItem>"
+           '</Topology><Geometry GeometryType="XYZ"><DataItem Dimensions="27 3" NumberType="Float" Format="XML">'
+           + " ".join(f"{c}" for p in pts for c in p) + "</DataItem></Geometry></Grid></Domain></Xdmf>")
+    path = tmp_path / "one_hex27.xdmf"
+    path.write_text(xml)
+    mesh, _, _ = read_xdmf_mesh(str(path))
+    assert mesh.order == 2 and mesh.geometry.dofmap.shape == (1, 27)
+    got = np.asarray(mesh.geometry.x)[mesh.geometry.dofmap[0]]
+    want = np.array([[nx / 2, ny / 2, nz / 2] for nz in range(3) for ny in range(3) for nx in range(3)])
+    assert np.array_equal(got, want)

@@ -1815,8 +1815,10 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   // per-cell geometry paths (affine, trilinear): about half the streamed size; at p >= 5 blocks of 8
   // elements, small enough for four / three / two blocks per CU at the register budgets of those
   // kernels (p=5: +3-5 % over 12, p=6: +19-20 %; profiles/r01_block_sweep.txt)
+  // (fp32, round 3: the fp64 block accumulator costs 4 more bytes of LDS per local dof; re-swept at 64^3,
+  // profiles/r03_experiments.md section 4: affine 8 / 8 / 4 elements at p = 5 / 6 / 7)
   static const int be_aff_hi[8] = {0, 0, 0, 0, 0, 8, 8, 8};
-  const int be_affine = (op->tdim == 3 && op->P >= 5) ? ((op->dtype == FUS_F32 && op->P == 5) ? 16 : be_aff_hi[op->P])
+  const int be_affine = (op->tdim == 3 && op->P >= 5) ? ((op->dtype == FUS_F32 && op->P == 7) ? 4 : be_aff_hi[op->P])
                                                       : be_stream / 2;
   const int gcs = affine_mesh ? 7 : (trilinear_mesh ? 21 : 0);
   // packed fp32 kernels (two elements per wave): degrees 5-7, per-cell geometry, LDS atomics, MFMA variants off
@@ -1827,8 +1829,9 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
            && (c->pack32 == 1 || (c->pack32 < 0 && !diag_mesh && (op->P == 5 || (op->P == 6 && affine_mesh))));
   // fp32 halves the LDS per block: the trilinear kernel takes 16 elements at p >= 5 (+9-12 %), the
   // affine one at p = 5 only (+5 %; 16 is 2-9 % slower at p = 6, 7)
+  // (round 3, fp64 accumulator: 16 / 8 / 8 elements at p = 5 / 6 / 7)
   const bool hi32 = op->dtype == FUS_F32 && op->tdim == 3 && op->P >= 5;
-  const int be_tri = hi32 ? 16 : be_affine;
+  const int be_tri = hi32 ? (op->P == 5 ? 16 : 8) : be_affine;
   const int be0 = c->block_elems > 0
                       ? c->block_elems
                       : ((trilinear_mesh || affine_mesh) && op->P == 4 && op->nfields == 1 && c->waves <= 0) ? 32
@@ -1842,8 +1845,9 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   // shared dofs than 16 / 4 -- the block kernel is 2-6 % slower, the step 1.5-3 % faster
   // (one operator input only: with two, such a block takes 92 KB of LDS and a CU holds one)
   // (fp32: the same 32 elements, +7-8 % over 24; eight waves on affine cells, four on the trilinear kernel)
+  // (fp32 trilinear too since the fp64 accumulator: 1.58 -> 1.62e10 with eight waves)
   const bool tri_p4 = (trilinear_mesh || affine_mesh) && op->P == 4 && op->nfields == 1 && c->waves <= 0
-                      && c->block_elems <= 0 && (op->dtype == FUS_F64 || affine_mesh);
+                      && c->block_elems <= 0;
   if (tri_p4)
     waves = 8;
   // blocks must fit the LDS budget (the CU's 160 KB, or half of it): shrink the block until they do
@@ -3030,7 +3034,10 @@ int fus_profile_get(fus_ctx* c, const char* name, double* total_ms, int64_t* cou
 } // extern "C"
 #endif  // !FUS_TU_DEGREE
 
-#if defined(FUS_TRACE) && defined(FUS_TU_DEGREE) && FUS_TU_DTYPE == 64
+#ifndef FUS_TRACE_BITS
+#define FUS_TRACE_BITS 64   // scalar type whose unit exports the trace (-DFUS_TRACE_BITS=32 for the fp32 kernels)
+#endif
+#if defined(FUS_TRACE) && defined(FUS_TU_DEGREE) && FUS_TU_DTYPE == FUS_TRACE_BITS
 // experiment builds: phase timestamps of the last k_block_op launch of this degree's unit
 extern "C" int fus_debug_trace(unsigned long long* out, long long nblocks)
 {

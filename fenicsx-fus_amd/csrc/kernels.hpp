@@ -358,7 +358,7 @@ template <typename T, int N, int OP, int ATOMIC, int NF>
 __device__ __forceinline__ void elem_compute2d(const ElemIn<T, N, OP, GEOM_STREAM, 2>& in,
                                                const T (&Drb)[N], const T (&Drc)[N],
                                                const T (&Dcb)[N], const T (&Dcc)[N],
-                                               const T* __restrict__ x_l, T* __restrict__ y_l,
+                                               const T* __restrict__ x_l, double* __restrict__ y_l,
                                                T* __restrict__ sA,
                                                const uint16_t* __restrict__ ldm_l,
                                                const T* __restrict__ cf_l,
@@ -403,7 +403,7 @@ __device__ __forceinline__ void elem_compute2d(const ElemIn<T, N, OP, GEOM_STREA
   else
     Y = cf * x_l[li] * in.g2[0];
   if (ATOMIC)
-    __hip_atomic_fetch_add(&y_l[li], Y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_add(&y_l[li], (double)Y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else
     y_l[li] += Y;
 }
@@ -437,11 +437,55 @@ __device__ __forceinline__ int rtix(int i0, int i1, int i2)
     return i0 * TS + i1 * N + i2;
 }
 
+// Cross-lane reads without LDS (DPP modifiers of the vector ALU): lane l receives x of another lane of its 16-lane
+// row.  CTRL: quad_perm (0x00-0xFF; broadcast of quad lane j = j * 0x55) or row_ror:n (0x120 + n: lane l reads lane
+// (l - n) & 15 of its row).  fp32: one v_mov_b32_dpp, which hipcc folds into the consuming v_fmac_f32; fp64: two moves.
+template <int CTRL>
+__device__ __forceinline__ float dpp_read(float x)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_read(double x)
+{
+  const uint64_t u = __builtin_bit_cast(uint64_t, x);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)u, CTRL, 0xf, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(u >> 32), CTRL, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+
+// sum_m cb[m] * (v of lane (b - m, c))  +  sum_j cc[j] * (w of lane (b, j)):  the index-1 and index-2 parts of a
+// contraction at N = 4, where lane (b, c) of an element sits at position 4 b + c of a 16-lane row
+template <typename T>
+__device__ __forceinline__ T dpp_contract_b(const T (&cb)[4], T v)
+{
+  T acc = cb[0] * v;
+  acc += cb[1] * dpp_read<0x124>(v);
+  acc += cb[2] * dpp_read<0x128>(v);
+  acc += cb[3] * dpp_read<0x12C>(v);
+  return acc;
+}
+template <typename T>
+__device__ __forceinline__ T dpp_contract_c(const T (&cc)[4], T w)
+{
+  T acc = cc[0] * dpp_read<0x00>(w);
+  acc += cc[1] * dpp_read<0x55>(w);
+  acc += cc[2] * dpp_read<0xAA>(w);
+  acc += cc[3] * dpp_read<0xFF>(w);
+  return acc;
+}
+
+// N = 4 (degree 3) per-cell geometry kernels: index-1 / index-2 contractions by wavefront shuffles (option / build flag
+// FUS_DPP4; profiles/r03_experiments.md section on DPP)
+#ifndef FUS_DPP4
+#define FUS_DPP4 0
+#endif
+
 template <typename T, int N, int OP, int ATOMIC, int NF, int GEOM>
 __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, const DTab<T, N>& Dk,
                                              const T (&Drb)[N], const T (&Drc)[N], const T (&Dcb)[N],
                                              const T (&Dcc)[N], const T* __restrict__ x_l,
-                                             T* __restrict__ y_l, T* __restrict__ sA,
+                                             double* __restrict__ y_l, T* __restrict__ sA,
                                              T* __restrict__ sB, const uint16_t* __restrict__ ldm_l,
                                              const T* __restrict__ cf_l, const T* __restrict__ x2_l,
                                              const T* __restrict__ cf2_l, const T* __restrict__ gc_l,
@@ -456,8 +500,19 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
   if (in.er < 0)
     return;
   TriLane<T> tri;
+#ifdef FUS_ABL_NOGC   // developer ablation (wrong results): the cell's map coefficients cost no LDS reads
+  if (GEOM == GEOM_TRILINEAR)
+  {
+    T fake[21];
+#pragma unroll
+    for (int i = 0; i < 21; ++i)
+      fake[i] = (i % 4 == 0) ? T(1) + pb * T(i) : T(0.01) * T(i) + pc;
+    tri.init(fake, pb, pc);
+  }
+#else
   if (GEOM == GEOM_TRILINEAR)
     tri.init(gc_l + in.er * 21, pb, pc);
+#endif
   int li[N];
 #pragma unroll
   for (int a = 0; a < N; ++a)
@@ -478,9 +533,16 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
     }
     else
     {
+#if defined(FUS_ABL_NOGS) || defined(FUS_ABL_NOGATHER)   // developer ablation (wrong results): no gather from x_l
+                                                         // (NOGS: and one scatter-add instead of N, below)
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        X[a] = T(li[a]) * T(1e-3);
+#else
 #pragma unroll
       for (int a = 0; a < N; ++a)
         X[a] = x_l[li[a]];
+#endif
     }
     // REMAP: the index-1 and index-2 contractions also run in registers.  Lane (b, c) re-reads the tile
     // as lane (a' = b, c) with index 1 along its registers (then as (a' = b, b' = c) with index 2 along
@@ -496,7 +558,65 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
     //   K x = sum_d g_d (M x .. x K1 x .. x M) x,   K1 = D^T diag(w) D  (the 1-D stiffness matrix, in Dk.d here),
     // three contractions instead of six and no pointwise transform.  Index 0 in registers; indices 1 and 2 as in
     // the re-mapped form below: one store of X, the two re-mapped reads, and one store + read per result.
-    if constexpr (GEOM == GEOM_DIAG)
+    if constexpr (N == 4 && FUS_DPP4 && GEOM != GEOM_DIAG && GEOM != GEOM_STREAM)
+    {
+      // Wavefront-shuffle form (north_star: "per-direction 1D contractions done with wavefront shuffles"): at N = 4 an
+      // element is one 16-lane DPP row, lane (b, c) at 4 b + c.  The index-1 contraction reads lanes (b - m, c) with
+      // row_ror:4m, the index-2 contraction the lanes of its own quad with quad_perm broadcasts; the lane's table
+      // entries for both come from the table in LDS once per element trip.  No exchange tile, no wave barrier.
+      T cb[4], cc[4], tb[4], tc[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+      {
+        const int jb = (b - m) & 3;
+        cb[m] = D_l[b * 4 + jb], tb[m] = D_l[jb * 4 + b];   // D[b][b-m] and its transpose D[b-m][b]
+        cc[m] = D_l[c * 4 + m], tc[m] = D_l[m * 4 + c];     // D[c][j], D[j][c]
+      }
+#pragma unroll
+      for (int q = 0; q < N; ++q)
+      {
+        T acc = T(0);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+          acc += Dk.d[q * N + i] * X[i];
+        F0[q] = acc;
+      }
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+      {
+        F1[a] = dpp_contract_b<T>(cb, X[a]);
+        F2[a] = dpp_contract_c<T>(cc, X[a]);
+      }
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+      {
+        if (GEOM == GEOM_TRILINEAR)
+          tri.transform(Dk.x[a], Dk.w[a] * wbc * cf, F0[a], F1[a], F2[a]);
+        else
+        {
+          T G6[6];
+#pragma unroll
+          for (int gi = 0; gi < 6; ++gi)
+            G6[gi] = gc_l[in.er * 7 + gi] * w3[a];
+          const T w0 = F0[a], w1 = F1[a], w2 = F2[a];
+          F0[a] = cf * (G6[0] * w0 + G6[1] * w1 + G6[2] * w2);
+          F1[a] = cf * (G6[1] * w0 + G6[3] * w1 + G6[4] * w2);
+          F2[a] = cf * (G6[2] * w0 + G6[4] * w1 + G6[5] * w2);
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+      {
+        T acc = T(0);
+#pragma unroll
+        for (int q = 0; q < N; ++q)
+          acc += Dk.d[q * N + a] * F0[q];
+        // transposed index-1 part: sum_j D[j][b] F1(a, j, c) -- lane (b - m, c) holds F1(a, b - m, c)
+        Y[a] = acc + dpp_contract_b<T>(tb, F1[a]) + dpp_contract_c<T>(tc, F2[a]);
+      }
+      (void)sA;
+    }
+    else if constexpr (GEOM == GEOM_DIAG)
     {
       constexpr int TS = tile_plane_stride<T, N>();
       const T g0 = gc_l[in.er * 7 + 0] * cf * wbc, g1 = gc_l[in.er * 7 + 3] * cf * wbc,
@@ -553,6 +673,44 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
       for (int a = 0; a < N; ++a)
         Y[a] += sA[rtix<N, TS>(a, b, c)];
     }
+#ifdef FUS_ABL_NOEXCH   // developer ablation (wrong results): the six contractions and the transform on the lane's own
+                         // registers, no exchange through the LDS tile and none of its wave barriers
+    else if constexpr (REMAP)
+    {
+      auto mul = [&](const T (&in)[N], T (&out)[N], bool tr)
+      {
+#pragma unroll
+        for (int q = 0; q < N; ++q)
+        {
+          T acc = T(0), dr[N];
+          if (tr)
+            dtab_row<T, N, 1>(Dk, q, dr);
+          else
+            dtab_row<T, N, 0>(Dk, q, dr);
+#pragma unroll
+          for (int i = 0; i < N; ++i)
+            acc += dr[i] * in[i];
+          out[q] = acc;
+        }
+      };
+      mul(X, F0, false), mul(X, F1, false), mul(X, F2, false);
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+      {
+        F1[a] += T(0.5) * F0[a], F2[a] -= T(0.25) * F0[a];
+        if (GEOM == GEOM_TRILINEAR)
+          tri.transform(Dk.x[a], Dk.w[a] * wbc * cf, F0[a], F1[a], F2[a]);
+        else
+          F0[a] *= cf * w3[a];
+      }
+      T Y1[N], Y2[N];
+      mul(F0, Y, true), mul(F1, Y1, true), mul(F2, Y2, true);
+#pragma unroll
+      for (int a = 0; a < N; ++a)
+        Y[a] += Y1[a] + Y2[a];
+      (void)sA;
+    }
+#endif
     else if constexpr (REMAP)
     {
       // plane stride of the tile: N^2, padded by one where the re-mapped accesses (lanes (b, c) at
@@ -613,8 +771,16 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
       for (int a = 0; a < N; ++a)
       {
+#ifdef FUS_ABL_NOTRANS   // developer ablation (wrong results): no per-point Jacobian / transform arithmetic
+        if (GEOM == GEOM_TRILINEAR)
+        {
+          const T sc = Dk.w[a] * wbc * cf * tri.j0[0];
+          F0[a] *= sc, F1[a] *= sc, F2[a] *= sc;
+        }
+#else
         if (GEOM == GEOM_TRILINEAR)
           tri.transform(Dk.x[a], Dk.w[a] * wbc * cf, F0[a], F1[a], F2[a]);
+#endif
         else
         {
           T G6[6];
@@ -789,11 +955,27 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
   }
   // scatter-add into the block accumulator (spectral_op.hpp:240-241); elements of one round
   // share no dof and rounds are ordered -> deterministic
+#if defined(FUS_ABL_NOGS) || defined(FUS_ABL_NOSCATTER)
+  {
+    T sum = T(0);
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      sum += Y[a];
+    __hip_atomic_fetch_add(&y_l[li[0]], (double)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+  }
+#endif
+#ifdef FUS_ABL_SCWRITE   // developer ablation (wrong results): the scatter as plain stores to the same addresses
+#pragma unroll
+  for (int a = 0; a < N; ++a)
+    y_l[li[a]] = (double)Y[a];
+  return;
+#endif
 #pragma unroll
   for (int a = 0; a < N; ++a)
   {
     if (ATOMIC)
-      __hip_atomic_fetch_add(&y_l[li[a]], Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&y_l[li[a]], (double)Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else
       y_l[li[a]] += Y[a];
   }
@@ -807,7 +989,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 // the memory operations of lanes without an element or a column).  Per-cell geometry (affine / trilinear).
 template <typename T, int N, int OP, int ATOMIC, int NF, int GEOM>
 __device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTab<T, N>& Dk, const T* __restrict__ x_l,
-                                                T* __restrict__ y_l, T* __restrict__ sA,
+                                                double* __restrict__ y_l, T* __restrict__ sA,
                                                 const uint16_t* __restrict__ ldm_l, const T* __restrict__ cf_l,
                                                 const T* __restrict__ x2_l, const T* __restrict__ cf2_l,
                                                 const T* __restrict__ gc_l, const T* __restrict__ D_l,
@@ -1114,7 +1296,7 @@ __device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTa
     for (int a = 0; a < N; ++a)
     {
       if (ATOMIC)
-        __hip_atomic_fetch_add(&y_l[li[a]], Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&y_l[li[a]], (double)Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       else
         y_l[li[a]] += Y[a];
     }
@@ -1141,7 +1323,7 @@ __device__ __forceinline__ F2 pk_abs(F2 x) { return F2{__builtin_fabsf(x[0]), __
 
 template <int N, int ATOMIC, int NF, int GEOM>
 __device__ __forceinline__ void elem_compute_pk(int e0, int e1, const DTab<float, N>& Dk, const float* __restrict__ x_l,
-                                                float* __restrict__ y_l, F2* __restrict__ sA,
+                                                double* __restrict__ y_l, F2* __restrict__ sA,
                                                 const uint16_t* __restrict__ ldm_l, const float* __restrict__ cf_l,
                                                 const float* __restrict__ x2_l, const float* __restrict__ cf2_l,
                                                 const float* __restrict__ gc_l, const float* __restrict__ w_l,
@@ -1343,9 +1525,9 @@ __device__ __forceinline__ void elem_compute_pk(int e0, int e1, const DTab<float
     Y[a] += sA[a * TS + p];
     if (ATOMIC)
     {
-      __hip_atomic_fetch_add(&y_l[li0[a]], Y[a][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&y_l[li0[a]], (double)Y[a][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (two)
-        __hip_atomic_fetch_add(&y_l[li1[a]], Y[a][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&y_l[li1[a]], (double)Y[a][1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     else
     {
@@ -1455,7 +1637,7 @@ __device__ __forceinline__ void mfma_tile_operands(T (&Bm)[4][2], const T* __res
 
 template <typename T, int N, int ATOMIC, int NF, int GEOM>
 __device__ __forceinline__ void elem_compute_mfma(const ElemIn<T, N, OP_STIFFNESS, GEOM>& in, const DTab<T, N>& Dk,
-                                                  const T* __restrict__ x_l, T* __restrict__ y_l,
+                                                  const T* __restrict__ x_l, double* __restrict__ y_l,
                                                   T* __restrict__ sA, const uint16_t* __restrict__ ldm_l,
                                                   const T* __restrict__ cf_l, const T* __restrict__ x2_l,
                                                   const T* __restrict__ cf2_l, const T* __restrict__ gc_l,
@@ -1610,7 +1792,7 @@ __device__ __forceinline__ void elem_compute_mfma(const ElemIn<T, N, OP_STIFFNES
     {
       Y[a] += sA[mfma_tix<N>(a, pb_i, pc_i)];
       if (ATOMIC)
-        __hip_atomic_fetch_add(&y_l[li[a]], Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&y_l[li[a]], (double)Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       else
         y_l[li[a]] += Y[a];
     }
@@ -1711,7 +1893,7 @@ __device__ __forceinline__ bool elem_stiff_fwd(const ElemIn<T, N, OP_STIFFNESS, 
 template <typename T, int N, int DL = 0, int ATOMIC = 1>
 __device__ __forceinline__ void elem_stiff_bwd(const DTab<T, N>& Dk, const T (&Dcb_)[N], const T (&Dcc_)[N],
                                                const T* __restrict__ D_l,
-                                               T* __restrict__ y_l, T* __restrict__ sA, int p, int b,
+                                               double* __restrict__ y_l, T* __restrict__ sA, int p, int b,
                                                int c, const int (&li)[N], const T (&F0)[N],
                                                const T (&F1)[N], const T (&F2)[N])
 {
@@ -1760,7 +1942,7 @@ __device__ __forceinline__ void elem_stiff_bwd(const DTab<T, N>& Dk, const T (&D
   for (int a = 0; a < N; ++a)
   {
     if (ATOMIC)
-      __hip_atomic_fetch_add(&y_l[li[a]], Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&y_l[li[a]], (double)Y[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     else
       y_l[li[a]] += Y[a];   // conflict-free rounds: elements of one round share no dof
   }
@@ -1939,6 +2121,12 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   KP q = (KP)__builtin_amdgcn_kernarg_segment_ptr();                             \
   asm volatile("" : "+s"(q))
   constexpr int GCS = geom_cell_stride(GEOM);               // per-cell geometry numbers (7 / 21 / 0)
+  // FUS_ACC: the block accumulator y_l is fp64 for every scalar type.  On gfx950 the LDS atomic ds_add_f32 is
+  // an order of magnitude slower than ds_add_f64 / ds_add_u32 / a plain store (fp32 p=6: a third of the kernel,
+  // profiles/r03_experiments.md section 3), so the fp32 kernels scatter-add with ds_add_f64 into an fp64 image and
+  // round once when the sums leave LDS (which also makes the fp32 element sum exact to fp32 rounding).
+  constexpr int AW = 8 / (int)sizeof(T);                    // accumulator entry in units of T
+  typedef double A2 __attribute__((ext_vector_type(2)));
   extern __shared__ __align__(16) unsigned char smem_raw[];
   // LDS carve, re-derived from the kernel arguments in every phase (nothing of it is carried around the
   // block loop in scalar registers)
@@ -1946,8 +2134,8 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   const int lds_nloc = q->A.lds_nloc, lds_nelem = q->A.lds_nelem, nwaves = q->A.waves;             \
   const int slots = (nwaves * 64 / LPE) * EPW * EPS;                                               \
   T* x_l = reinterpret_cast<T*>(smem_raw);                                                         \
-  T* y_l = x_l + lds_nloc;                                                                         \
-  T* x2_l = y_l + lds_nloc; /* second input (NF == 2 only) */                                      \
+  double* y_l = reinterpret_cast<double*>(x_l + lds_nloc); /* accumulator: fp64 for every T (FUS_ACC) */ \
+  T* x2_l = reinterpret_cast<T*>(y_l + lds_nloc); /* second input (NF == 2 only) */                \
   T* scratch = x2_l + (NF == 2 ? lds_nloc : 0);                                                    \
   T* D_l = scratch + (size_t)slots * SLOT; /* derivative table (tiles: SLOT entries each) */       \
   T* cf_l = D_l + N2; /* per-element coefficient(s) */                                             \
@@ -1977,7 +2165,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   const bool active = s < EPW;                                                                     \
   const int myslot = (wave * EPW + (active ? s : 0)) * EPS;                                        \
   /* exchange tiles follow x_l, y_l (, x2_l); one per element slot */                              \
-  T* sA = reinterpret_cast<T*>(smem_raw) + (size_t)(NF == 2 ? 3 : 2) * q->A.lds_nloc                \
+  T* sA = reinterpret_cast<T*>(smem_raw) + (size_t)((NF == 2 ? 2 : 1) + AW) * q->A.lds_nloc         \
           + (size_t)myslot * SLOT;                                                                 \
   T* sB = sA
 
@@ -2094,7 +2282,9 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
     const int n16 = (sh.nelem * Nd * 2 + 15) >> 4;
     const U4* lsrc = reinterpret_cast<const U4*>(q->A.ldm + sh.ldm_off);
     const int ngc = sh.nelem * GCS;
-    // LDS stores
+    // LDS stores; the accumulator is cleared (16 bytes per store)
+    for (int i = tid; i < (sh.nloc + 1) / 2; i += nthr)
+      reinterpret_cast<A2*>(y_l)[i] = A2(0.0);
 #pragma unroll
     for (int u = 0; u < UI; ++u)
       if (tid + u * nthr < nvec)
@@ -2102,7 +2292,6 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
         reinterpret_cast<V2*>(x_l)[tid + u * nthr] = L.xi[u];
         if (NF == 2)
           reinterpret_cast<V2*>(x2_l)[tid + u * nthr] = L.xi2[u];
-        reinterpret_cast<V2*>(y_l)[tid + u * nthr] = V2(T(0));
       }
 #pragma unroll
     for (int u = 0; u < UL; ++u)
@@ -2143,7 +2332,6 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
       x_l[sh.nint - 1] = L.xtail;
       if (NF == 2)
         x2_l[sh.nint - 1] = L.xtail2;
-      y_l[sh.nint - 1] = T(0);
     }
 #pragma unroll
     for (int u = 0; u < US; ++u)
@@ -2152,7 +2340,6 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
         x_l[sh.nint + tid + u * nthr] = L.xs[u];
         if (NF == 2)
           x2_l[sh.nint + tid + u * nthr] = L.xs2[u];
-        y_l[sh.nint + tid + u * nthr] = T(0);
       }
     // leftovers of large blocks (higher degrees), again with the loads of a batch ahead of its stores
     constexpr int UB = 8;
@@ -2174,7 +2361,6 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
           reinterpret_cast<V2*>(x_l)[base + u * nthr] = v[u];
           if (NF == 2)
             reinterpret_cast<V2*>(x2_l)[base + u * nthr] = v2[u];
-          reinterpret_cast<V2*>(y_l)[base + u * nthr] = V2(T(0));
         }
     }
     for (int base = tid + US * nthr; base < nsh; base += nthr * UB)
@@ -2198,7 +2384,6 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
           x_l[sh.nint + base + u * nthr] = v[u];
           if (NF == 2)
             x2_l[sh.nint + base + u * nthr] = v2[u];
-          y_l[sh.nint + base + u * nthr] = T(0);
         }
     }
     for (int base = tid + UL * nthr; base < n16; base += nthr * UB)
@@ -2283,9 +2468,8 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   else
   {
     FUS_TID();
-    typedef T V2z __attribute__((ext_vector_type(2)));
     for (int i = tid; i < (M.sh.nloc + 1) / 2; i += nthr)
-      reinterpret_cast<V2z*>(y_l)[i] = V2z(T(0));
+      reinterpret_cast<A2*>(y_l)[i] = A2(0.0);
   }
 #else
   p_commit(qc, M, L, first);
@@ -2460,9 +2644,12 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   {
     V2* bg = reinterpret_cast<V2*>(bvec + int_off);
     for (int i = tid; i < nvec; i += nthr)
-      bg[i] = reinterpret_cast<const V2*>(y_l)[i];
+    {
+      const A2 a2 = reinterpret_cast<const A2*>(y_l)[i];
+      bg[i] = V2{(T)a2[0], (T)a2[1]};
+    }
     if (tid == 0 && (sh.nint & 1))
-      bvec[int_off + sh.nint - 1] = y_l[sh.nint - 1];
+      bvec[int_off + sh.nint - 1] = (T)y_l[sh.nint - 1];
   }
   else
   {
@@ -2508,7 +2695,10 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
       { return E.on ? __builtin_nontemporal_load(reinterpret_cast<const V2*>(ptr + E.o)) : V2(T(0)); };
 #endif
       auto lds = [&](const T* l) -> V2 { return E.on ? reinterpret_cast<const V2*>(l)[i] : V2(T(0)); };
-      E.bv = lds(y_l);
+      {
+        const A2 a2 = E.on ? reinterpret_cast<const A2*>(y_l)[i] : A2(0.0);
+        E.bv = V2{(T)a2[0], (T)a2[1]};
+      }
       constexpr bool WV = NF == 2;   // Westervelt operands possible (S.mn1 decides at run time)
       if ((WV && S.mn1) || STAGE == 4 || STAGE == 6)
         E.us = lds(x_l);             // the stage input u_n of the interior dofs is still in LDS
@@ -2584,7 +2774,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
     };
     // the last dof of an odd interior range: the one-dof form of the same update
     if (tid == 0 && (sh.nint & 1))
-      (void)stage_update_dof<T, STAGE>((int64_t)int_off + sh.nint - 1, y_l[sh.nint - 1], S.minv, S.vn, S.un, S.u0,
+      (void)stage_update_dof<T, STAGE>((int64_t)int_off + sh.nint - 1, (T)y_l[sh.nint - 1], S.minv, S.vn, S.un, S.u0,
                                        S.v0, S.u_, S.v_, S.adt, S.bdt, (NF == 2) ? S.m0 : nullptr,
                                        (NF == 2) ? S.mn1 : nullptr, LeanRK<T>{S.b0dt, S.r0, S.r1});
     if constexpr (EPI2)
@@ -2611,9 +2801,9 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
 #pragma unroll
   for (int u = 0; u < US; ++u)
     if (ppv[u] >= 0)
-      partial[ppv[u]] = y_l[sh.nint + tid + u * nthr];
+      partial[ppv[u]] = (T)y_l[sh.nint + tid + u * nthr];
   for (int k = tid + US * nthr; k < nsh; k += nthr)
-    partial[pp[k]] = y_l[sh.nint + k];
+    partial[pp[k]] = (T)y_l[sh.nint + k];
   }
   FUS_TRACE_END(blk);
   if (!has_next)

@@ -69,7 +69,8 @@ struct Layout
   size_t lds_bytes(size_t sizeofT, int nfields = 1, int geom_cell_stride = 0) const
   {
     const size_t ne = ((size_t)max_nelem + 7) & ~(size_t)7;
-    return (size_t)(1 + nfields) * ((max_nloc + 1) & ~1) * sizeofT   // x_l (, x2_l), y_l
+    return (size_t)nfields * ((max_nloc + 1) & ~1) * sizeofT          // x_l (, x2_l)
+           + (size_t)((max_nloc + 1) & ~1) * 8                        // y_l: fp64 for every T (kernels.hpp FUS_ACC)
            + (size_t)slots * ((tdim == 3 && N == 7 && sizeofT == 4) ? N * 56 : Nd + N) * sizeofT   // per-element exchange tile (kernels.hpp tile_slot_entries)
            + (size_t)N * N * sizeofT + nfields * ne * sizeofT  // derivative table, coefficients
            + (geom_cell_stride ? ((size_t)geom_cell_stride * ne + (N <= 8 ? 16 : 24)) * sizeofT : 0)  // per-cell geometry, 1-D weights + points (8 or 12 slots each)

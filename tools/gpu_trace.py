@@ -14,14 +14,15 @@ from fenicsxfus_amd import _abi  # noqa: E402
 geom = sys.argv[1] if len(sys.argv) > 1 else "stream"
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 4
 n = int(sys.argv[3]) if len(sys.argv) > 3 else 64
+dtype = np.float32 if (len(sys.argv) > 4 and sys.argv[4] == "f32") else np.float64   # f32: build with -DFUS_TRACE_BITS=32
 L = 0.12
-mesh = fa.BoxMesh([0, 0, 0], [L, L, L], (n, n, n))
+mesh = fa.BoxMesh([0, 0, 0], [L, L, L], (n, n, n), dtype=dtype)
 V = fa.FunctionSpace(mesh, P)
 tags = fa.tag_box_boundary(mesh)
 nc = mesh.num_cells
 dt = 0.5 * (L / n) / (1500.0 * P**2)
 ctx = fa.Context(0, geometry=geom)
-m = fa.LinearSpectralExplicit(mesh, tags, P, np.full(nc, 1500.0), np.full(nc, 1000.0), 0.5e6, 6e4, 1500.0, 4, dt, V=V, ctx=ctx)
+m = fa.LinearSpectralExplicit(mesh, tags, P, np.full(nc, 1500.0, dtype), np.full(nc, 1000.0, dtype), 0.5e6, 6e4, 1500.0, 4, dt, V=V, ctx=ctx)
 m.init()
 m.rk4_steps(0.0, dt, 5)
 ctx.synchronize()

@@ -477,9 +477,48 @@ __device__ __forceinline__ T dpp_contract_c(const T (&cc)[4], T w)
 
 // N = 4 (degree 3) per-cell geometry kernels: index-1 / index-2 contractions by wavefront shuffles (option / build flag
 // FUS_DPP4; profiles/r03_experiments.md section on DPP)
+// 0: never, 1: the general affine kernel (where it measured faster: -4 % fp64, -7 % fp32 at 64^3; the trilinear kernel
+// lost 2 % in fp64 and was even in fp32), 2: every per-cell geometry kernel
 #ifndef FUS_DPP4
-#define FUS_DPP4 0
+#define FUS_DPP4 1
 #endif
+__host__ __device__ constexpr bool use_dpp4(int N, int geom)
+{
+  return N == 4 && ((FUS_DPP4 == 1 && geom == GEOM_AFFINE) || (FUS_DPP4 == 2 && (geom == GEOM_AFFINE || geom == GEOM_TRILINEAR)));
+}
+
+// N = 8: lane (b, c) at 8 b + c.  Value of lane (b, j) of the lane's own group of eight, through ds_swizzle in bit-mask
+// mode (and_mask 0x18 keeps the group, or_mask j selects the lane; the instruction runs in the LDS pipe but touches no
+// LDS memory).  A/B only (build flag FUS_SWZ8): 16 swizzles per fp64 value and contraction against 2 tile accesses.
+#ifndef FUS_SWZ8
+#define FUS_SWZ8 0
+#endif
+template <int J>
+__device__ __forceinline__ float swz8_read(float x)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, x), (J << 5) | 0x18));
+}
+template <int J>
+__device__ __forceinline__ double swz8_read(double x)
+{
+  const uint64_t u = __builtin_bit_cast(uint64_t, x);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(uint32_t)u, (J << 5) | 0x18);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_swizzle((int)(uint32_t)(u >> 32), (J << 5) | 0x18);
+  return __builtin_bit_cast(double, ((uint64_t)hi << 32) | lo);
+}
+template <typename T>
+__device__ __forceinline__ T swz8_contract_c(const T (&cc)[8], T w)
+{
+  T acc = cc[0] * swz8_read<0>(w);
+  acc += cc[1] * swz8_read<1>(w);
+  acc += cc[2] * swz8_read<2>(w);
+  acc += cc[3] * swz8_read<3>(w);
+  acc += cc[4] * swz8_read<4>(w);
+  acc += cc[5] * swz8_read<5>(w);
+  acc += cc[6] * swz8_read<6>(w);
+  acc += cc[7] * swz8_read<7>(w);
+  return acc;
+}
 
 template <typename T, int N, int OP, int ATOMIC, int NF, int GEOM>
 __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, const DTab<T, N>& Dk,
@@ -558,7 +597,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
     //   K x = sum_d g_d (M x .. x K1 x .. x M) x,   K1 = D^T diag(w) D  (the 1-D stiffness matrix, in Dk.d here),
     // three contractions instead of six and no pointwise transform.  Index 0 in registers; indices 1 and 2 as in
     // the re-mapped form below: one store of X, the two re-mapped reads, and one store + read per result.
-    if constexpr (N == 4 && FUS_DPP4 && GEOM != GEOM_DIAG && GEOM != GEOM_STREAM)
+    if constexpr (use_dpp4(N, GEOM))
     {
       // Wavefront-shuffle form (north_star: "per-direction 1D contractions done with wavefront shuffles"): at N = 4 an
       // element is one 16-lane DPP row, lane (b, c) at 4 b + c.  The index-1 contraction reads lanes (b - m, c) with
@@ -730,12 +769,20 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
       for (int a = 0; a < N; ++a)
         sA[rtix<N, TS>(a, b, c)] = X[a];
       FUS_WAVE_SYNC();
-      T Tb[N], Uc[N];
+      constexpr bool SWZ = (N == 8) && FUS_SWZ8;   // index-2 contractions by ds_swizzle instead of the tile (A/B)
+      T Tb[N], Uc[N], swc[8], swt[8];
+      if constexpr (SWZ)
+      {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          swc[j] = D_l[c * N + j], swt[j] = D_l[j * N + c];   // D[c][j], D[j][c]
+      }
 #pragma unroll
       for (int k = 0; k < N; ++k)
       {
         Tb[k] = sA[rtix<N, TS>(b, k, c)];
-        Uc[k] = sA[rtix<N, TS>(b, c, k)];
+        if constexpr (!SWZ)
+          Uc[k] = sA[rtix<N, TS>(b, c, k)];
       }
       FUS_WAVE_SYNC();
 #pragma unroll
@@ -752,6 +799,14 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
       for (int a = 0; a < N; ++a)
         F1[a] = sA[rtix<N, TS>(a, b, c)];
+      if constexpr (SWZ)
+      {
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+          F2[a] = swz8_contract_c<T>(swc, X[a]);   // d/dX2 at the lane's own points (a, b, c)
+      }
+      else
+      {
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int q = 0; q < N; ++q)
@@ -767,6 +822,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
       for (int a = 0; a < N; ++a)
         F2[a] = sA[rtix<N, TS>(a, b, c)];
+      }
       // stiffness::transform (spectral_op.hpp:113-130)
 #pragma unroll
       for (int a = 0; a < N; ++a)
@@ -827,6 +883,14 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
           acc += dc[q] * F0[q];
         Y[a] = acc;
       }
+      if constexpr (SWZ)
+      {
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+          Y[a] += swz8_contract_c<T>(swt, F2[a]);   // sum_j D[j][c] F2(a, b, j)
+      }
+      else
+      {
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
@@ -850,6 +914,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
       for (int a = 0; a < N; ++a)
         Y[a] += sA[rtix<N, TS>(a, b, c)];
+      }
     }
     else
     {
@@ -962,6 +1027,19 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
     for (int a = 0; a < N; ++a)
       sum += Y[a];
     __hip_atomic_fetch_add(&y_l[li[0]], (double)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return;
+  }
+#endif
+#ifdef FUS_ABL_RTN32   // developer probe (wrong results): fp32 scatter with the RETURNING fp32 LDS atomic
+  if constexpr (sizeof(T) == 4)
+  {
+    float seen = 0.0f;
+#pragma unroll
+    for (int a = 0; a < N; ++a)
+      seen += __hip_atomic_fetch_add(reinterpret_cast<float*>(y_l) + li[a], (float)Y[a], __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (seen == 1.2345e30f)
+      y_l[0] = seen;
     return;
   }
 #endif

@@ -113,7 +113,10 @@ def test_fp32_two_slabs_in_process(orc, P, n):
 def _full_size_properties(geometry, P, ncell, L, dtype=np.float64, tol_sym=1e-10, tol_one=1e-11):
     """Size-independent properties of the operator at a benchmark size: K 1 = 0, sum(K x) = 0, symmetry,
     sum(m) = volume."""
-    m = fa.BoxMesh([0, 0, 0], [L, L, L], (ncell,) * 3, dtype=dtype)
+    ncell = (ncell,) * 3 if np.isscalar(ncell) else tuple(ncell)     # cells per axis; L = edge of the first axis' box
+    h = L / ncell[0]
+    vol = h**3 * ncell[0] * ncell[1] * ncell[2]
+    m = fa.BoxMesh([0, 0, 0], [h * k for k in ncell], ncell, dtype=dtype)
     V = fa.FunctionSpace(m, P)
     ctx = fa.Context(0, geometry=geometry)
     d = fa.SpectralOperatorData(V, ctx)
@@ -131,7 +134,7 @@ def _full_size_properties(geometry, P, ncell, L, dtype=np.float64, tol_sym=1e-10
     zy = z.astype(np.float64) @ y.astype(np.float64)
     assert abs(zy - x.astype(np.float64) @ yz.astype(np.float64)) < tol_sym * abs(zy)
     mm = d.mass(np.ones(n, dtype), np.ones(nc, dtype), np.zeros(n, dtype))
-    assert abs(mm.astype(np.float64).sum() - L**3) < (1e-12 if dtype == np.float64 else 1e-5) * L**3
+    assert abs(mm.astype(np.float64).sum() - vol) < (1e-12 if dtype == np.float64 else 1e-5) * vol
     info = d.info()
     d.close()
     ctx.close()
@@ -150,6 +153,14 @@ def test_full_size_properties_p7(geometry):
     same block layout and kernels as 128^3."""
     n, info = _full_size_properties(geometry, 7, 64, 0.12)
     assert n == (64 * 7 + 1) ** 3 and info["nblocks"] == 262144 // 8
+
+
+def test_full_size_properties_config3_slab():
+    """One rank's 32 x 256 x 256 x-slab of BASELINE configs[3] (256^3 p=4 fp64 over 8 GPUs): 135 M dofs, 65 536 blocks.
+    (The whole 256^3 box on one GPU -- 1.08e9 dofs -- is checked by tools/gpu_config3_full.py; its layout alone
+    takes minutes of host time, too long for this suite.)"""
+    n, info = _full_size_properties("trilinear", 4, (32, 256, 256), 0.12 * 32 / 64)
+    assert n == 129 * 1025 * 1025 and info["nblocks"] == 32 * 256 * 256 // 32
 
 
 def test_full_size_properties_p6_fp32():

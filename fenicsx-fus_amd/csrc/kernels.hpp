@@ -493,6 +493,25 @@ __host__ __device__ constexpr bool use_dpp4(int N, int geom)
 #ifndef FUS_SWZ8
 #define FUS_SWZ8 0
 #endif
+
+// N = 8, fp64: the index-1 contraction on the matrix cores straight from the registers, v_mfma_f64_4x4x4_4b_f64 (four
+// independent 4x4x4 products per instruction: no padding at N = 8).  Lane layout of the instruction, found by brute force
+// (tools/mfma4_probe.hip, profiles/r03_mfma4_lane_layout.txt):  A[i][k] at lane 16 k + 4 blk + i,  B[k][j] at lane
+// 16 k + 4 blk + j,  D[i][j] at lane 16 i + 4 blk + j.  With the kernel's own lane = 8 b + c the B operand of block
+// (beta = b & 1, c >> 2) IS the lane's register X[a]: k = b >> 1, j = c & 3 -- the four b of one parity; the other
+// parity's values come from lane ^ 8 (DPP row_ror:8), and the result D (row i = q >> 1 of parity beta) lands in lane
+// (q, c): no exchange tile, no wave barrier.  out(q, c) = sum_b M[q][b] in(b, c) with
+//   a_own = M[2 i + beta][2 k + beta],  a_swp = M[2 i + beta][2 k + 1 - beta]   (i = lane & 3, k = lane >> 4).
+#ifndef FUS_MF4
+#define FUS_MF4 1
+#endif
+__device__ __forceinline__ double mf4_contract_b(double a_own, double a_swp, double v)
+{
+  const double w = dpp_read<0x128>(v);   // the value of lane ^ 8: the other parity of b
+  double acc = __builtin_amdgcn_mfma_f64_4x4x4f64(a_swp, w, 0.0, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a_own, v, acc, 0, 0, 0);
+}
+__device__ __forceinline__ float mf4_contract_b(float, float, float v) { return v; }   // (fp64 only)
 template <int J>
 __device__ __forceinline__ float swz8_read(float x)
 {
@@ -770,7 +789,17 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
         sA[rtix<N, TS>(a, b, c)] = X[a];
       FUS_WAVE_SYNC();
       constexpr bool SWZ = (N == 8) && FUS_SWZ8;   // index-2 contractions by ds_swizzle instead of the tile (A/B)
+      // index-1 contractions on the matrix cores (mf4_contract_b): the trilinear kernel, where it measured +5 ... +7 %
+      // (the general affine kernel and the diagonal-metric form were even: profiles/r03_experiments.md section 6)
+      constexpr bool MF4 = (N == 8) && sizeof(T) == 8 && FUS_MF4 && GEOM == GEOM_TRILINEAR;
       T Tb[N], Uc[N], swc[8], swt[8];
+      T mf_own = T(0), mf_swp = T(0), mt_own = T(0), mt_swp = T(0);
+      if constexpr (MF4)
+      {
+        const int ln = b * N + c, be = b & 1, mi = 2 * (ln & 3) + be, mk = 2 * (ln >> 4);
+        mf_own = D_l[mi * N + mk + be], mf_swp = D_l[mi * N + mk + 1 - be];       // D[q][b]
+        mt_own = D_l[(mk + be) * N + mi], mt_swp = D_l[(mk + 1 - be) * N + mi];   // D^T
+      }
       if constexpr (SWZ)
       {
 #pragma unroll
@@ -780,10 +809,19 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
       for (int k = 0; k < N; ++k)
       {
-        Tb[k] = sA[rtix<N, TS>(b, k, c)];
+        if constexpr (!MF4)
+          Tb[k] = sA[rtix<N, TS>(b, k, c)];
         if constexpr (!SWZ)
           Uc[k] = sA[rtix<N, TS>(b, c, k)];
       }
+      if constexpr (MF4)
+      {
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+          F1[a] = mf4_contract_b(mf_own, mf_swp, X[a]);   // d/dX1 at the lane's own points (a, b, c)
+      }
+      else
+      {
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int q = 0; q < N; ++q)
@@ -799,6 +837,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
 #pragma unroll
       for (int a = 0; a < N; ++a)
         F1[a] = sA[rtix<N, TS>(a, b, c)];
+      }
       if constexpr (SWZ)
       {
 #pragma unroll
@@ -853,6 +892,21 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
         }
       }
       // transposed contractions, the same way round
+      if constexpr (MF4)
+      {
+#pragma unroll
+        for (int a = 0; a < N; ++a)
+        {
+          T acc = mf4_contract_b(mt_own, mt_swp, F1[a]), dc[N];   // sum_q D[q][b] F1(a, q, c)
+          dtab_row<T, N, 1>(Dk, a, dc);
+#pragma unroll
+          for (int q = 0; q < N; ++q)
+            acc += dc[q] * F0[q];
+          Y[a] = acc;
+        }
+      }
+      else
+      {
       FUS_WAVE_SYNC();
 #pragma unroll
       for (int a = 0; a < N; ++a)
@@ -882,6 +936,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
         for (int q = 0; q < N; ++q)
           acc += dc[q] * F0[q];
         Y[a] = acc;
+      }
       }
       if constexpr (SWZ)
       {

@@ -437,9 +437,14 @@ static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, 
   const int b0 = blk_begin, nb = blk_count;
   if constexpr (P >= 8)
   {
-    // degrees 8-10: two waves per element (kernels.hpp, elem_compute_hi), per-cell geometry only
-    if (op->tdim != 3 || !(op->affine || op->trilinear))
-      return fail(FUS_ERR_ARG, "degrees 8-10: first-order hexahedra (affine or trilinear geometry path) only");
+    // degrees 8-10: two waves per element (kernels.hpp, elem_compute_hi); per-cell geometry where the mesh allows,
+    // per-point factors streamed otherwise (second-order geometry, option "geometry" = 1)
+    if (op->tdim != 3)
+      return fail(FUS_ERR_ARG, "degrees 8-10: hexahedra only");
+    if (!(op->affine || op->trilinear))
+      return op->deterministic
+                 ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_STREAM>(op, geo, coef, x, bvec, S, b0, nb)
+                 : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_STREAM>(op, geo, coef, x, bvec, S, b0, nb);
     const T* gc = static_cast<const T*>(op->d_Gc);
     if (op->affine)
       return op->deterministic
@@ -1772,12 +1777,16 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   {
     // degrees 8-10 (two waves per element): 4-element blocks, an even number of waves
     const bool aff = affine_mesh;
+    const bool tri8 = !affine_mesh && c->geometry != 1 && op->geom_order == 1;   // else: per-point factors streamed
+    const int gcs8 = aff ? 7 : (tri8 ? 21 : 0);
     int waves8 = c->waves > 0 ? std::min(4, (c->waves + 1) & ~1) : 4;
-    for (int be = c->block_elems > 0 ? c->block_elems : 4;; be = (be + 1) / 2)
+    // (fp64 distorted cells at degree 8: 8-element blocks, +8.5 % over 4 -- fewer shared dofs; profiles/r03_experiments.md 7)
+    const int be_hi = (op->P == 8 && op->dtype == FUS_F64 && tri8) ? 8 : 4;
+    for (int be = c->block_elems > 0 ? c->block_elems : be_hi;; be = (be + 1) / 2)
     {
       std::string err = build_layout(op->L, op->P, op->ncells, op->ndofs, op->h_dofmap.data(), cen.data(), be, waves8,
                                      force_shared, op->tdim);
-      const bool too_big = err.empty() ? op->L.lds_bytes(op->ts, op->nfields, aff ? 7 : 21) + 64 > 160 * 1024
+      const bool too_big = err.empty() ? op->L.lds_bytes(op->ts, op->nfields, gcs8) + 64 > 160 * 1024
                                        : err.find("65535") != std::string::npos;
       if (too_big && be > 1)
         continue;
@@ -2177,9 +2186,8 @@ int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_
     return fail(FUS_ERR_ARG, "dtype must be FUS_F32 or FUS_F64");
   if (geom_order != 1 && geom_order != 2)
     return fail(FUS_ERR_ARG, "geometry order must be 1 (2^tdim vertices) or 2 (3^tdim nodes, tensor order)");
-  if (P >= 8 && (tdim != 3 || geom_order != 1 || c->geometry == 1))
-    return fail(FUS_ERR_ARG, "degrees 8-10: first-order hexahedra through the per-cell geometry kernels (option "
-                             "\"geometry\" 0 or 2) only");
+  if (P >= 8 && tdim != 3)
+    return fail(FUS_ERR_ARG, "degrees 8-10: hexahedra only (quadrilaterals go to degree 7)");
   if (ncells <= 0 || ndofs <= 0 || nnodes <= 0)
     return fail(FUS_ERR_ARG, "empty mesh");
   const int N = P + 1;

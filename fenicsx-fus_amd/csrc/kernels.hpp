@@ -185,6 +185,10 @@ enum
 // waves per SIMD the GEOM_TRILINEAR block kernel is compiled for: 4 (128 VGPRs) up to degree 5, 2 above
 // (degrees 6 / 7 need 161 / 184 VGPRs; capping 7 at 168 measured no gain)
 #define FUS_TRI_WAVES(P) ((P) <= 5 ? 4 : 2)
+// waves per SIMD the kernels of the degrees 8-10 are compiled for
+#ifndef FUS_HI_WAVES
+#define FUS_HI_WAVES 1
+#endif
 // Geometry source of the block operator
 //   GEOM_STREAM: per-point factors G / detJw streamed from HBM (any trilinear mesh; the reference's
 //                data path, precompute.hpp:101-213)
@@ -328,7 +332,7 @@ __device__ __forceinline__ void elem_fetch(ElemIn<T, N, OP, GEOM, TD>& in, int e
     }
     return;
   }
-  if (GEOM == GEOM_STREAM && er >= 0)
+  if (GEOM == GEOM_STREAM && er >= 0 && N2 <= 64)   // (degrees 8-10 read their factors where used: elem_compute_hi)
   {
     const int64_t e = elem_off + er;
     if (OP == OP_STIFFNESS)
@@ -1127,9 +1131,10 @@ __device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTa
                                                 const T* __restrict__ x2_l, const T* __restrict__ cf2_l,
                                                 const T* __restrict__ gc_l, const T* __restrict__ D_l,
                                                 const T* __restrict__ w_l, const T* __restrict__ pt_l, int p, int b,
-                                                int c)
+                                                int c, const T* __restrict__ geo = nullptr, int elem_off = 0)
 {
-  static_assert(is_aff(GEOM) || GEOM == GEOM_TRILINEAR, "per-cell geometry kernels");
+  // GEOM_STREAM (any first- or second-order hexahedron, precompute.hpp:101-213): the lane's per-point factors are read
+  // from HBM where the transform uses them (no register prefetch: correctness path of the Qdegree range, not a tuned one)
   constexpr int N2 = N * N, Nd = N * N * N;
   const bool on = er_ >= 0 && has_col;
   const int er = er_ >= 0 ? er_ : 0;
@@ -1358,11 +1363,21 @@ __device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTa
           tri.transform(pt_l[a], w_l[a] * wbc * cf, F0[a], F1[a], F2[a]);
         else
         {
-          const T w3 = w_l[a] * w_l[bb] * w_l[cc];
           T G6[6];
+          if constexpr (GEOM == GEOM_STREAM)
+          {
+            const T* __restrict__ Ge = geo + (int64_t)(elem_off + er) * (6 * Nd);
+  #pragma unroll
+            for (int gi = 0; gi < 6; ++gi)
+              G6[gi] = on ? Ge[g_index<T, N>(gi * N + a, pp)] : T(0);
+          }
+          else
+          {
+          const T w3 = w_l[a] * w_l[bb] * w_l[cc];
   #pragma unroll
           for (int gi = 0; gi < 6; ++gi)
             G6[gi] = gc_l[er * 7 + gi] * w3;   // affine cell: G(q) = Gc w_q
+          }
           const T w0 = F0[a], w1 = F1[a], w2 = F2[a];
           F0[a] = cf * (G6[0] * w0 + G6[1] * w1 + G6[2] * w2);
           F1[a] = cf * (G6[1] * w0 + G6[3] * w1 + G6[4] * w2);
@@ -1420,8 +1435,14 @@ __device__ __forceinline__ void elem_compute_hi(int er_, bool has_col, const DTa
     // mass::transform (spectral_op.hpp:19-26)
 #pragma unroll
     for (int a = 0; a < N; ++a)
-      Y[a] = cf * x_l[li[a]]
-             * (GEOM == GEOM_TRILINEAR ? tri.detw(pt_l[a], w_l[a] * wbc) : gc_l[er * 7 + 6] * (w_l[a] * w_l[bb] * w_l[cc]));
+    {
+      T dj;
+      if constexpr (GEOM == GEOM_STREAM)
+        dj = on ? geo[(int64_t)(elem_off + er) * Nd + a * N2 + pp] : T(0);
+      else
+        dj = GEOM == GEOM_TRILINEAR ? tri.detw(pt_l[a], w_l[a] * wbc) : gc_l[er * 7 + 6] * (w_l[a] * w_l[bb] * w_l[cc]);
+      Y[a] = cf * x_l[li[a]] * dj;
+    }
   }
   if (on)
   {
@@ -2220,7 +2241,7 @@ __device__ __forceinline__ void load_stage_args(const KArgs<T, N> __attribute__(
 // derivative-table rows read from LDS where used.
 // TD = 2: the same block machinery for quadrilateral elements (Nd = N^2, GEOM_STREAM only).
 template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3, int MF = 0, int PK = 0>
-__global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P >= 8) ? 1 : (P <= 4 && is_aff(GEOM))
+__global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P >= 8) ? FUS_HI_WAVES : (P <= 4 && is_aff(GEOM))
                                                             ? 4
                                                             : ((GEOM == GEOM_TRILINEAR || (is_aff(GEOM) && P <= 6)) ? FUS_TRI_WAVES(P) : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1)))
 k_block_op(const KArgs<T, P + 1> kernel_args)
@@ -2238,7 +2259,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   constexpr int LPE = (N2 <= 64) ? 64 : 128;
   constexpr int SLOT = tile_slot_entries<T, N, TD>();   // entries of one element's exchange tile
   static_assert(N2 <= 128, "degrees up to 10");
-  static_assert(LPE == 64 || (TD == 3 && GEOM != GEOM_STREAM && !MF), "degrees 8-10: hexahedra, per-cell geometry");
+  static_assert(LPE == 64 || (TD == 3 && !MF), "degrees 8-10: hexahedra");
   // packed fp32 (elem_compute_pk): a wave works on two elements at once
   static_assert(!PK || (sizeof(T) == 4 && EPW == 1 && LPE == 64 && TD == 3 && OP == OP_STIFFNESS && ATOMIC && !MF
                         && GEOM != GEOM_STREAM),
@@ -2666,7 +2687,8 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   {                                                                                                \
     if constexpr (LPE == 128)                                                                      \
       elem_compute_hi<T, N, OP, ATOMIC, NF, GEOM>(in.er, s == 0, Dk, x_l, y_l, sA, ldm_l, cf_l,    \
-                                                  x2_l, cf2_l, gc_l, D_l, w_l, pt_l, p, b, c);     \
+                                                  x2_l, cf2_l, gc_l, D_l, w_l, pt_l, p, b, c, geo, \
+                                                  elem_off);                                       \
     else if constexpr (MF && TD == 3 && OP == OP_STIFFNESS)                                        \
       elem_compute_mfma<T, N, ATOMIC, NF, GEOM>(in, Dk, x_l, y_l, sA, ldm_l, cf_l, x2_l, cf2_l,    \
                                                 gc_l, w3, D_l, wbc, pb, pc, p, lane);              \

@@ -6,6 +6,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -127,3 +128,33 @@ def test_bench_json_contract():
     # the other geometry paths are timed beside the headline at N = 1
     assert d["other_geometry"]["value"] > 0 and d["streamed_geometry"]["value"] > 0
     assert "trilinear" in d["config"]["geometry"]
+
+
+def test_compulsory_bytes_model_and_slab_workload():
+    """bench.py's compulsory-bytes roofline (the bytes THIS layout must move) on hand-computable layout statistics, and the
+    --cells-xyz workload (one rank's x-slab of the 256^3 configs as a box of its own) -- host logic only."""
+    sys.path.insert(0, ROOT)
+    import argparse
+
+    import bench
+
+    info = {"interior_dofs": 1000, "shared_dofs": 200, "pairs": 450, "shapes": 2, "nblocks": 10}
+    nc, N3, s = 80, 125, 8
+    blk, sh, det = bench.compulsory_bytes(info, nc, N3, s, "trilinear", "linear", lean=True)
+    assert det["x_block_local"] == (1000 + 450) * 8 and det["gather_index_and_partial_position"] == 8 * 450
+    assert det["partial_sums_written"] == 450 * 8 and det["geometry_per_cell"] == 21 * 8 * 80
+    assert det["stage_update_streams_interior"] == (4 + 7 + 9 + 6) / 4 * 8 * 1000          # lean RK4 stage kinds 4, 5, 6, 3
+    assert abs(blk - sum(det.values())) < 1e-9 and sh == (450 + (5 + 7 + 10 + 6) / 4 * 200) * 8
+    blk_s, _, det_s = bench.compulsory_bytes(info, nc, N3, s, "stream", "linear", lean=False)
+    assert det_s["geometry_per_cell"] == 6 * N3 * 8 * 80 and det_s["stage_update_streams_interior"] == (7 + 10 + 10 + 6) / 4 * 8 * 1000
+    assert blk_s > blk
+    # two gathered operator inputs (Lossy), two more vector reads (Westervelt)
+    _, _, det_l = bench.compulsory_bytes(info, nc, N3, s, "affine", "lossy")
+    assert det_l["x_block_local"] == 2 * (1000 + 450) * 8 and det_l["geometry_per_cell"] == 7 * 8 * 80
+    args = argparse.Namespace(P=2, global_cells=0, cells=4, cells_xyz=(2, 4, 3), medium="skull")
+    mesh, V, tags, c, rho, freq, p0, dt = bench.workload(args, 0, 1)
+    assert mesh.num_cells == 24 and V.num_dofs == 5 * 9 * 7 and len(c) == 24
+    h = 0.12 / 64
+    assert abs(dt - (1 / freq) / np.ceil((1 / freq) / (0.5 * h / (2800.0 * 4)))) < 1e-18
+    mesh2, V2, *_ = bench.workload(args, 1, 2)                  # weak scaling: the same box per rank
+    assert mesh2.num_cells == 24 and V2.global_offset == 2 * 2 * 9 * 7

@@ -185,6 +185,12 @@ enum
 // waves per SIMD the GEOM_TRILINEAR block kernel is compiled for: 4 (128 VGPRs) up to degree 5, 2 above
 // (degrees 6 / 7 need 161 / 184 VGPRs; capping 7 at 168 measured no gain)
 #define FUS_TRI_WAVES(P) ((P) <= 5 ? 4 : 2)
+// the same for the fp32 kernels of the degrees 6 and 7 (158-174 VGPRs when compiled for two waves per SIMD: three
+// resident 4-wave blocks per CU; FUS_TRI32_WAVES = 4 caps them at 128)
+#ifndef FUS_TRI32_WAVES
+#define FUS_TRI32_WAVES 2
+#endif
+#define FUS_TRI_WAVES_T(T, P) ((sizeof(T) == 4 && (P) >= 6) ? FUS_TRI32_WAVES : FUS_TRI_WAVES(P))
 // waves per SIMD the kernels of the degrees 8-10 are compiled for
 #ifndef FUS_HI_WAVES
 #define FUS_HI_WAVES 1
@@ -2243,7 +2249,7 @@ __device__ __forceinline__ void load_stage_args(const KArgs<T, N> __attribute__(
 template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3, int MF = 0, int PK = 0>
 __global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P >= 8) ? FUS_HI_WAVES : (P <= 4 && is_aff(GEOM))
                                                             ? 4
-                                                            : ((GEOM == GEOM_TRILINEAR || (is_aff(GEOM) && P <= 6)) ? FUS_TRI_WAVES(P) : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1)))
+                                                            : ((GEOM == GEOM_TRILINEAR || (is_aff(GEOM) && P <= 6)) ? FUS_TRI_WAVES_T(T, P) : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1)))
 k_block_op(const KArgs<T, P + 1> kernel_args)
 {
   (void)kernel_args;

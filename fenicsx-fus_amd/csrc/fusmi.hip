@@ -439,8 +439,10 @@ static int launch_block_op(fus_op* op, const T* geo, const T* coef, const T* x, 
   {
     // degrees 8-10: two waves per element (kernels.hpp, elem_compute_hi); per-cell geometry where the mesh allows,
     // per-point factors streamed otherwise (second-order geometry, option "geometry" = 1)
-    if (op->tdim != 3)
-      return fail(FUS_ERR_ARG, "degrees 8-10: hexahedra only");
+    if (op->tdim == 2)   // quadrilaterals: an element's N^2 nodes span two waves (elem_compute2d, HI)
+      return op->deterministic
+                 ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_STREAM, 2>(op, geo, coef, x, bvec, S, b0, nb)
+                 : launch_block_op_v<T, P, OP, 1, STAGE, NF, GEOM_STREAM, 2>(op, geo, coef, x, bvec, S, b0, nb);
     if (!(op->affine || op->trilinear))
       return op->deterministic
                  ? launch_block_op_v<T, P, OP, 0, STAGE, NF, GEOM_STREAM>(op, geo, coef, x, bvec, S, b0, nb)
@@ -1777,11 +1779,11 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
   {
     // degrees 8-10 (two waves per element): 4-element blocks, an even number of waves
     const bool aff = affine_mesh;
-    const bool tri8 = !affine_mesh && c->geometry != 1 && op->geom_order == 1;   // else: per-point factors streamed
+    const bool tri8 = !affine_mesh && c->geometry != 1 && op->geom_order == 1 && op->tdim == 3;   // else: per-point factors streamed
     const int gcs8 = aff ? 7 : (tri8 ? 21 : 0);
     int waves8 = c->waves > 0 ? std::min(4, (c->waves + 1) & ~1) : 4;
     // (fp64 distorted cells at degree 8: 8-element blocks, +8.5 % over 4 -- fewer shared dofs; profiles/r03_experiments.md 7)
-    const int be_hi = (op->P == 8 && op->dtype == FUS_F64 && tri8) ? 8 : 4;
+    const int be_hi = op->tdim == 2 ? 32 : ((op->P == 8 && op->dtype == FUS_F64 && tri8) ? 8 : 4);
     for (int be = c->block_elems > 0 ? c->block_elems : be_hi;; be = (be + 1) / 2)
     {
       std::string err = build_layout(op->L, op->P, op->ncells, op->ndofs, op->h_dofmap.data(), cen.data(), be, waves8,
@@ -2186,8 +2188,6 @@ int fus_op_create(fus_ctx* c, int tdim, int P, int dtype, int64_t ncells, int64_
     return fail(FUS_ERR_ARG, "dtype must be FUS_F32 or FUS_F64");
   if (geom_order != 1 && geom_order != 2)
     return fail(FUS_ERR_ARG, "geometry order must be 1 (2^tdim vertices) or 2 (3^tdim nodes, tensor order)");
-  if (P >= 8 && tdim != 3)
-    return fail(FUS_ERR_ARG, "degrees 8-10: hexahedra only (quadrilaterals go to degree 7)");
   if (ncells <= 0 || ndofs <= 0 || nnodes <= 0)
     return fail(FUS_ERR_ARG, "empty mesh");
   const int N = P + 1;

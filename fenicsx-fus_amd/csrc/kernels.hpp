@@ -364,7 +364,10 @@ __device__ __forceinline__ void elem_fetch(ElemIn<T, N, OP, GEOM, TD>& in, int e
 // both derivative directions exchange through the element's LDS tile
 // (cpp/fenicsx-sf-naive/common/spectral_op.hpp:273-323 with the transform of :195-207; G = (xx, xy,
 // yy) with xx pairing with the derivative along tensor index 0).
-template <typename T, int N, int OP, int ATOMIC, int NF>
+// HI (N^2 > 64, degrees 8-10): the element's N^2 nodes span two waves -- lane pair index p, columns p < N^2 --, the tile
+// exchanges are fenced by workgroup barriers and nothing returns early (every wave of the workgroup meets every barrier;
+// has_col / in.er guard the memory operations of lanes without a node or an element).
+template <typename T, int N, int OP, int ATOMIC, int NF, bool HI = false>
 __device__ __forceinline__ void elem_compute2d(const ElemIn<T, N, OP, GEOM_STREAM, 2>& in,
                                                const T (&Drb)[N], const T (&Drc)[N],
                                                const T (&Dcb)[N], const T (&Dcc)[N],
@@ -373,49 +376,69 @@ __device__ __forceinline__ void elem_compute2d(const ElemIn<T, N, OP, GEOM_STREA
                                                const uint16_t* __restrict__ ldm_l,
                                                const T* __restrict__ cf_l,
                                                const T* __restrict__ x2_l,
-                                               const T* __restrict__ cf2_l, int p, int b, int c)
+                                               const T* __restrict__ cf2_l, int p, int b, int c,
+                                               bool has_col = true)
 {
   constexpr int Nd = N * N;
-  if (in.er < 0)
+#define FUS_SYNC2D()                                                                               \
+  do                                                                                               \
+  {                                                                                                \
+    if constexpr (HI)                                                                              \
+      __syncthreads();                                                                             \
+    else                                                                                           \
+      FUS_WAVE_SYNC();                                                                             \
+  } while (0)
+  if (!HI && in.er < 0)
     return;
-  const int li = ldm_l[in.er * Nd + p];
-  const T cf = (NF == 2) ? T(1) : cf_l[in.er];
+  const bool on = in.er >= 0 && has_col;
+  const int er = in.er >= 0 ? in.er : 0, pp = has_col ? p : 0, bb = has_col ? b : 0, cc = has_col ? c : 0;
+  const int li = on ? (int)ldm_l[er * Nd + pp] : 0;
+  const T cf = (NF == 2) ? T(1) : cf_l[er];
   T Y;
   if (OP == OP_STIFFNESS)
   {
-    const T X = (NF == 2) ? cf_l[in.er] * x_l[li] + cf2_l[in.er] * x2_l[li] : x_l[li];
-    sA[p] = X;
-    FUS_WAVE_SYNC();
+    const T X = (NF == 2) ? cf_l[er] * x_l[li] + cf2_l[er] * x2_l[li] : x_l[li];
+    if (on)
+      sA[pp] = X;
+    FUS_SYNC2D();
     T d0 = T(0), d1 = T(0);
 #pragma unroll
     for (int j = 0; j < N; ++j)
     {
-      d0 += Drb[j] * sA[j * N + c];
-      d1 += Drc[j] * sA[b * N + j];
+      d0 += Drb[j] * sA[j * N + cc];
+      d1 += Drc[j] * sA[bb * N + j];
     }
     const T F0 = cf * (in.g2[0] * d0 + in.g2[1] * d1);
     const T F1 = cf * (in.g2[1] * d0 + in.g2[2] * d1);
-    FUS_WAVE_SYNC();
-    sA[p] = F0;
-    FUS_WAVE_SYNC();
+    FUS_SYNC2D();
+    if (on)
+      sA[pp] = F0;
+    FUS_SYNC2D();
     T acc = T(0);
 #pragma unroll
     for (int j = 0; j < N; ++j)
-      acc += Dcb[j] * sA[j * N + c];
-    FUS_WAVE_SYNC();
-    sA[p] = F1;
-    FUS_WAVE_SYNC();
+      acc += Dcb[j] * sA[j * N + cc];
+    FUS_SYNC2D();
+    if (on)
+      sA[pp] = F1;
+    FUS_SYNC2D();
 #pragma unroll
     for (int j = 0; j < N; ++j)
-      acc += Dcc[j] * sA[b * N + j];
+      acc += Dcc[j] * sA[bb * N + j];
     Y = acc;
+    if constexpr (HI)
+      __syncthreads();   // the tile is free for the next element
   }
   else
     Y = cf * x_l[li] * in.g2[0];
-  if (ATOMIC)
-    __hip_atomic_fetch_add(&y_l[li], (double)Y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  else
-    y_l[li] += Y;
+#undef FUS_SYNC2D
+  if (on)
+  {
+    if (ATOMIC)
+      __hip_atomic_fetch_add(&y_l[li], (double)Y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    else
+      y_l[li] += Y;
+  }
 }
 
 // Index of entry (i0, i1, i2) of an element's exchange tile in the re-mapped contractions.  N = 8: the tile is read and
@@ -2265,7 +2288,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   constexpr int LPE = (N2 <= 64) ? 64 : 128;
   constexpr int SLOT = tile_slot_entries<T, N, TD>();   // entries of one element's exchange tile
   static_assert(N2 <= 128, "degrees up to 10");
-  static_assert(LPE == 64 || (TD == 3 && !MF), "degrees 8-10: hexahedra");
+  static_assert(LPE == 64 || !MF, "degrees 8-10: no matrix-core variants");
   // packed fp32 (elem_compute_pk): a wave works on two elements at once
   static_assert(!PK || (sizeof(T) == 4 && EPW == 1 && LPE == 64 && TD == 3 && OP == OP_STIFFNESS && ATOMIC && !MF
                         && GEOM != GEOM_STREAM),
@@ -2691,7 +2714,10 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
 #define FUS_ELEM_COMPUTE(in)                                                                       \
   do                                                                                               \
   {                                                                                                \
-    if constexpr (LPE == 128)                                                                      \
+    if constexpr (LPE == 128 && TD == 2)                                                           \
+      elem_compute2d<T, N, OP, ATOMIC, NF, true>(in, Drb, Drc, Dcb, Dcc, x_l, y_l, sA, ldm_l,      \
+                                                 cf_l, x2_l, cf2_l, p, b, c, s == 0);              \
+    else if constexpr (LPE == 128)                                                                 \
       elem_compute_hi<T, N, OP, ATOMIC, NF, GEOM>(in.er, s == 0, Dk, x_l, y_l, sA, ldm_l, cf_l,    \
                                                   x2_l, cf2_l, gc_l, D_l, w_l, pt_l, p, b, c, geo, \
                                                   elem_off);                                       \

@@ -69,8 +69,8 @@ std::string build_layout(Layout& L, int P, int64_t ncells, int64_t ndofs,
   L.ncells = ncells, L.ndofs = ndofs;
   L.waves = std::max(1, waves);
   L.epw = std::max(1, 64 / (L.N * L.N));
-  // degrees 8-10 on hexahedra: a tensor plane has more than 64 columns and two waves share an element
-  L.slots = (tdim == 3 && L.N * L.N > 64) ? std::max(1, L.waves / 2) : L.waves * L.epw;
+  // degrees 8-10: a tensor plane (an element, for quadrilaterals) has more than 64 columns and two waves share an element
+  L.slots = (L.N * L.N > 64) ? std::max(1, L.waves / 2) : L.waves * L.epw;
   L.slots *= std::max(1, slot_factor);   // packed fp32 kernels: two elements per lane group and trip
   const int Nd = L.Nd;
   if (block_elems < 1)

@@ -2,8 +2,8 @@
 a tensor plane has 81-121 columns, two waves work on one element (kernels.hpp, elem_compute_hi).
 Operators and the RK4 loop against the oracle on affine and distorted first-order hexahedra, both
 accumulation modes, fp32; per-point factors streamed (option "geometry" = stream, and second-order -- 27-node --
-hexahedra, which always stream) so that the Qdegree range has no holes on hexahedra; the remaining restriction (no
-quadrilaterals at these degrees) is reported as an error."""
+hexahedra, which always stream) so that the Qdegree range has no holes (quadrilaterals at these degrees:
+tests/test_gpu_quad2d.py); a degree beyond the reference's map is reported as an error."""
 import numpy as np
 import pytest
 
@@ -143,9 +143,6 @@ def test_streamed_geometry_rk4_high_degree(orc):
 
 def test_unsupported_combinations_are_errors(orc):
     c = fa.Context(0)
-    p2 = Problem(orc, (3, 3), 8)
-    with pytest.raises(fa.FusError):
-        fa.SpectralOperatorData(p2.V, c)           # quadrilaterals: degrees <= 7
     p11 = Problem(orc, (1, 1, 1), 11)
     with pytest.raises(fa.FusError):
         fa.SpectralOperatorData(p11.V, c)          # the reference's map ends at 10

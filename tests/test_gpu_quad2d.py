@@ -42,6 +42,43 @@ def test_quad_operators_vs_oracle(orc, ctx, P, perturb):
     d.close()
 
 
+@pytest.mark.parametrize("P", [8, 9, 10])
+@pytest.mark.parametrize("perturb,det,dtype,tol", [(0.0, 0, np.float64, TOL_OP), (0.15, 1, np.float64, TOL_OP),
+                                                   (0.15, 0, np.float32, 2e-4)])
+def test_quad_operators_high_degree(orc, P, perturb, det, dtype, tol):
+    """Degrees 8-10 on quadrilaterals (the naive reference's Qdegree map goes to 10): an element's 81-121 nodes span two
+    waves, tile exchanges fenced by workgroup barriers (elem_compute2d, HI)."""
+    pr = Problem(orc, (7, 5), P, hi=[1.5, 1.0], perturb=perturb, dtype=dtype)
+    rng = np.random.default_rng(P)
+    x = rng.standard_normal(pr.ndofs).astype(dtype)
+    coef = rng.uniform(0.5, 2.0, pr.mesh.num_cells).astype(dtype)
+    c = fa.Context(0, deterministic=det)
+    d = fa.SpectralOperatorData(pr.V, c)
+    y0 = rng.standard_normal(pr.ndofs).astype(dtype)
+    assert relmax(fa.StiffnessSpectral2D(pr.V, d)(x, coef, y0.copy()), y0 + pr.K(x, coef)) < tol
+    assert relmax(fa.MassSpectral2D(pr.V, d)(x, coef, y0.copy()), y0 + pr.M(x, coef)) < tol
+    d.close()
+    c.close()
+
+
+def test_quad_linear_rk4_high_degree(orc):
+    """LinearSpectral2D at p = 8 through the two-wave kernel with the fused stage update."""
+    P, n, hi, nsteps = 8, (5, 4), [0.02, 0.016], 8
+    pr = Problem(orc, n, P, hi=hi, perturb=0.1)
+    nc = pr.mesh.num_cells
+    c0, rho0 = np.full(nc, 1500.0), np.full(nc, 1000.0)
+    tags = tag_box_boundary(pr.mesh)
+    m, src, absb, coeff = pr.linear_model_vectors(c0, rho0, tags)
+    dt = 0.4 * (hi[0] / n[0]) / (1500.0 * P**2)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    orc.linear_rk4(2, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, 0.5e6, 6e4, 1500.0, 0.0, nsteps * dt * (1 + 1e-12), dt, u, v)
+    mdl = fa.LinearSpectralExplicit(pr.mesh, tags, P, c0, rho0, 0.5e6, 6e4, 1500.0, 4, dt, V=pr.V)
+    mdl.init()
+    mdl.rk4_steps(0.0, dt, nsteps)
+    assert np.abs(u).max() > 0 and relmax(mdl.u_sol().x.array, u) < TOL_RK and relmax(mdl.v_n.x.array, v) < TOL_RK
+    mdl.close()
+
+
 @pytest.mark.parametrize("det", [0, 1])
 @pytest.mark.parametrize("be,w", [(16, 1), (50, 2), (300, 4), (1000, 8)])
 def test_quad_block_shapes(orc, be, w, det):

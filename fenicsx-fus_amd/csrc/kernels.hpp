@@ -2674,6 +2674,10 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   }
   __syncthreads();
   FUS_STAMP(blk, 1);
+#ifdef FUS_STAGGER   // developer probe: the second half of an 8-wave workgroup starts its trips FUS_STAGGER x 64 cycles later
+  if (tid0 >= 256)
+    __builtin_amdgcn_s_sleep(FUS_STAGGER);
+#endif
   // lane-dependent rows/columns of the derivative table, quadrature weights and points of the lane's
   // tensor column (the tables stay in LDS from the first block on)
   T Drb[N], Drc[N], Dcb[N], Dcc[N], w3[N];

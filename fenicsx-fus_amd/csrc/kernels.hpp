@@ -192,6 +192,10 @@ enum
 #endif
 #define FUS_TRI_WAVES_T(T, P) ((sizeof(T) == 4 && (P) >= 6) ? FUS_TRI32_WAVES : FUS_TRI_WAVES(P))
 // waves per SIMD the kernels of the degrees 8-10 are compiled for
+// interior ranges of the fused stage update in flight per pass at the degrees >= 5 (one operator input)
+#ifndef FUS_EPIU
+#define FUS_EPIU 4
+#endif
 #ifndef FUS_HI_WAVES
 #define FUS_HI_WAVES 1
 #endif
@@ -2968,15 +2972,22 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
       (void)stage_update_dof<T, STAGE>((int64_t)int_off + sh.nint - 1, (T)y_l[sh.nint - 1], S.minv, S.vn, S.un, S.u0,
                                        S.v0, S.u_, S.v_, S.adt, S.bdt, (NF == 2) ? S.m0 : nullptr,
                                        (NF == 2) ? S.mn1 : nullptr, LeanRK<T>{S.b0dt, S.r0, S.r1});
-    if constexpr (EPI2)
+    // degrees >= 5 (4-wave workgroups, blocks of up to 3375 dofs: four to five passes per thread): FUS_EPIU ranges per pass --
+    // at p=7 the one-range loop made the epilogue the longest phase of a block (6.9 of 19.2 us: a memory round trip per pass)
+    // (A/B at 64^3, one box: four ranges +3 % at p=7 fp64, +4 % fp32 p=6, +1.5 % fp64 p=6; six +14 % at fp32 p=7 and even at
+    // fp64; eight spills: -25 %.  profiles/r03_experiments.md section 11)
+    constexpr int EPIU = EPI2 ? 2 : ((P >= 5 && NF == 1) ? ((sizeof(T) == 4 && P == 7) ? FUS_EPIU + 2 : FUS_EPIU) : 1);
+    if constexpr (EPIU > 1)
     {
-      for (int i = tid; i < nvec; i += 2 * nthr)
+      for (int i = tid; i < nvec; i += EPIU * nthr)
       {
-        Epi E0, E1;
-        epi_load(i, E0);
-        epi_load(i + nthr, E1);
-        epi_store(E0);
-        epi_store(E1);
+        Epi E[EPIU];
+#pragma unroll
+        for (int u = 0; u < EPIU; ++u)
+          epi_load(i + u * nthr, E[u]);
+#pragma unroll
+        for (int u = 0; u < EPIU; ++u)
+          epi_store(E[u]);
       }
     }
     else

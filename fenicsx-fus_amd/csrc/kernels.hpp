@@ -192,9 +192,12 @@ enum
 #endif
 #define FUS_TRI_WAVES_T(T, P) ((sizeof(T) == 4 && (P) >= 6) ? FUS_TRI32_WAVES : FUS_TRI_WAVES(P))
 // waves per SIMD the kernels of the degrees 8-10 are compiled for
-// interior ranges of the fused stage update in flight per pass at the degrees >= 5 (one operator input)
+// interior ranges of the fused stage update in flight per pass at the degrees >= 6 (one operator input, per-cell geometry)
 #ifndef FUS_EPIU
 #define FUS_EPIU 4
+#endif
+#ifndef FUS_EPIU_F32P7AFF
+#define FUS_EPIU_F32P7AFF 2
 #endif
 #ifndef FUS_HI_WAVES
 #define FUS_HI_WAVES 1
@@ -218,6 +221,28 @@ enum
   GEOM_DIAG = 3
 };
 __host__ __device__ constexpr bool is_aff(int geom) { return geom == GEOM_AFFINE || geom == GEOM_DIAG; }
+
+template <typename T>
+__host__ __device__ constexpr int epiu_of(int P, int geom, int nf)
+{
+  // measured per kernel at 64^3 (profiles/r03_experiments.md section 11): where the kernel has no registers to spare
+  // (p=5: compiled for four waves per SIMD; the streamed kernels) more ranges spill or cost a resident wave
+  if (nf != 1 || geom == GEOM_STREAM || P < 5)
+    return 1;
+  if (P == 5)
+    return (sizeof(T) == 4 && geom == GEOM_TRILINEAR) ? FUS_EPIU : 1;   // (the packed fp32 kernel: +4.5 %)
+  if (sizeof(T) == 4 && P == 7)
+    return geom == GEOM_TRILINEAR ? FUS_EPIU + 2 : FUS_EPIU_F32P7AFF;
+  return FUS_EPIU;
+}
+// the stage update's HBM operands of the first pass requested BEFORE the barrier that ends the element trips (their
+// round trip runs under the barrier wait): fp64 at the degrees <= 5 (+1.3 % trilinear / +4.3 % affine at p=4, +1.4 / +4 %
+// at p=5); even or slightly negative elsewhere (fp32 p=4 -1.5 %, p=7 fp64 -2 %: the operands are live across the barrier)
+template <typename T>
+__host__ __device__ constexpr bool epi_early(int P)
+{
+  return sizeof(T) == 8 && P <= 5;
+}
 
 // numbers per cell held in LDS by the per-cell geometry modes
 __host__ __device__ constexpr int geom_cell_stride(int geom)
@@ -2789,28 +2814,6 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
     }
   }
 #undef FUS_ELEM_COMPUTE
-  __syncthreads();
-  FUS_STAMP(blk, 2);
-
-  // ---- phase 2: the next block of this workgroup -- its prologue loads travel while this block is
-  // written out ----
-  {
-    // (always executed, with every load predicated on has_next: the staged registers are then defined on
-    // every path and not live across the trips)
-    FUS_KARGS(qn);
-    Meta Mn{};
-    if (has_next)
-      Mn = meta_of(qn, blk_next);
-#ifdef FUS_PROBE_PFREE
-    if constexpr (!IDX_EARLY)
-      p_idx(qn, Mn, false, gi_n);
-    p_load(qn, Mn, L, false, false, gi_n);
-#else
-    if constexpr (!IDX_EARLY)
-      p_idx(qn, Mn, has_next, gi_n);
-    p_load(qn, Mn, L, false, has_next, gi_n);
-#endif
-  }
   {
   // this block's epilogue operands (arguments, LDS carve and block data re-derived: see FUS_KARGS)
   FUS_KARGS(qe);
@@ -2835,35 +2838,6 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
 
   // ---- epilogue: each dof written once ----
   const int nvec = sh.nint >> 1;
-  if (STAGE == STAGE_NONE)
-  {
-    V2* bg = reinterpret_cast<V2*>(bvec + int_off);
-    for (int i = tid; i < nvec; i += nthr)
-    {
-      const A2 a2 = reinterpret_cast<const A2*>(y_l)[i];
-      bg[i] = V2{(T)a2[0], (T)a2[1]};
-    }
-    if (tid == 0 && (sh.nint & 1))
-      bvec[int_off + sh.nint - 1] = (T)y_l[sh.nint - 1];
-  }
-  else
-  {
-    // boundary terms of block-interior dofs (Linear.hpp:205; forms.py:38-39 collocated):
-    // b += g(t) src - abs * v_stage ; every entry is a distinct dof
-    const int k0 = S.blk_bnd_off[blk], k1 = S.blk_bnd_off[blk + 1];
-    if (k1 > k0)
-    {
-      const T* vstage = stage_is_first(STAGE) ? S.v0 : S.vn;
-      for (int k = k0 + tid; k < k1; k += nthr)
-      {
-        const int gi = S.bnd_idx[k];
-        T add = S.gval * S.bnd_src[k] - S.bnd_abs[k] * vstage[gi];
-        if (NF == 2)
-          add += S.dgval * S.bnd_src2[k];
-        y_l[gi - int_off] += add;
-      }
-      __syncthreads();
-    }
     // fused stage update on the contiguous interior range (16-byte accesses)
     // degrees <= 4, one operator input: two interior ranges per pass, the loads of both in flight before
     // the first store (+1-3 % on the per-cell geometry paths; with the second input's extra operands
@@ -2875,8 +2849,13 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
       int i, o;
       V2 bv, mi, w, a0, b0, au, av, m1, m0v, us;
     };
-    auto epi_load = [&](int i, Epi& E) __attribute__((always_inline))
+    // part 1: the operands from HBM (issued BEFORE the barrier that ends the trips: they do not depend on the block's
+    // sums, and their round trip then runs under the barrier wait and the boundary terms); part 2: the sums / stage input
+    // from LDS; part 0: both
+    auto epi_load = [&](int i, Epi& E, int part) __attribute__((always_inline))
     {
+      if (part != 2)
+      {
       // (every field is assigned on every path -- zeros where the range has ended -- so that none of them
       // looks live across the block loop to the register allocator)
       E.on = i < nvec;
@@ -2889,18 +2868,11 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
       auto ld = [&](const T* ptr) -> V2
       { return E.on ? __builtin_nontemporal_load(reinterpret_cast<const V2*>(ptr + E.o)) : V2(T(0)); };
 #endif
-      auto lds = [&](const T* l) -> V2 { return E.on ? reinterpret_cast<const V2*>(l)[i] : V2(T(0)); };
-      {
-        const A2 a2 = E.on ? reinterpret_cast<const A2*>(y_l)[i] : A2(0.0);
-        E.bv = V2{(T)a2[0], (T)a2[1]};
-      }
       constexpr bool WV = NF == 2;   // Westervelt operands possible (S.mn1 decides at run time)
-      if ((WV && S.mn1) || STAGE == 4 || STAGE == 6)
-        E.us = lds(x_l);             // the stage input u_n of the interior dofs is still in LDS
       if (STAGE == 0)
         E.a0 = ld(S.u0), E.b0 = ld(S.v0);
       else if (STAGE == 4)
-        E.a0 = E.us, E.b0 = ld(S.v0);
+        E.b0 = ld(S.v0);
       else
         E.w = ld(S.vn);
       if (WV && S.mn1)
@@ -2915,6 +2887,17 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
         E.a0 = ld(S.u0), E.b0 = ld(S.v0);
       else if (STAGE == 6)
         E.av = ld(S.v_), E.a0 = ld(S.u0), E.b0 = ld(S.v0);
+      }
+      if (part != 1)
+      {
+        constexpr bool WV2 = NF == 2;
+        const A2 a2 = E.on ? reinterpret_cast<const A2*>(y_l)[E.i] : A2(0.0);
+        E.bv = V2{(T)a2[0], (T)a2[1]};
+        if ((WV2 && S.mn1) || STAGE == 4 || STAGE == 6)
+          E.us = E.on ? reinterpret_cast<const V2*>(x_l)[E.i] : V2(T(0));   // the stage input u_n of the interior dofs is still in LDS
+        if (STAGE == 4)
+          E.a0 = E.us;
+      }
     };
     auto epi_store = [&](const Epi& E) __attribute__((always_inline))
     {
@@ -2967,37 +2950,91 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
         st(S.vn, kv * S.adt + E.b0);
       }
     };
+    // degrees >= 6 (4-wave workgroups, blocks of up to 3375 dofs: four to five passes per thread): several ranges per pass --
+    // at p=7 the one-range loop made the epilogue the longest phase of a block (6.9 of 19.2 us: a memory round trip per
+    // pass).  Only where the kernel has registers to spare: at p=5 (compiled for four waves per SIMD) and on the streamed
+    // kernels four ranges spill or cost a resident wave (-45 % / -30 %); profiles/r03_experiments.md section 11.
+    constexpr int EPIU = EPI2 ? 2 : epiu_of<T>(P, GEOM, NF);
+    constexpr bool EARLY = epi_early<T>(P);
+    Epi Ef[EPIU];
+    if (EARLY && STAGE != STAGE_NONE)
+    {
+#pragma unroll
+      for (int u = 0; u < EPIU; ++u)
+        epi_load(tid + u * nthr, Ef[u], 1);
+    }
+  __syncthreads();   // every element of the block has been accumulated
+  FUS_STAMP(blk, 2);
+
+  // ---- phase 2: the next block of this workgroup -- its prologue loads travel while this block is
+  // written out ----
+  {
+    // (always executed, with every load predicated on has_next: the staged registers are then defined on
+    // every path and not live across the trips)
+    FUS_KARGS(qn);
+    Meta Mn{};
+    if (has_next)
+      Mn = meta_of(qn, blk_next);
+#ifdef FUS_PROBE_PFREE
+    if constexpr (!IDX_EARLY)
+      p_idx(qn, Mn, false, gi_n);
+    p_load(qn, Mn, L, false, false, gi_n);
+#else
+    if constexpr (!IDX_EARLY)
+      p_idx(qn, Mn, has_next, gi_n);
+    p_load(qn, Mn, L, false, has_next, gi_n);
+#endif
+  }
+  if (STAGE == STAGE_NONE)
+  {
+    V2* bg = reinterpret_cast<V2*>(bvec + int_off);
+    for (int i = tid; i < nvec; i += nthr)
+    {
+      const A2 a2 = reinterpret_cast<const A2*>(y_l)[i];
+      bg[i] = V2{(T)a2[0], (T)a2[1]};
+    }
+    if (tid == 0 && (sh.nint & 1))
+      bvec[int_off + sh.nint - 1] = (T)y_l[sh.nint - 1];
+  }
+  else
+  {
+    // boundary terms of block-interior dofs (Linear.hpp:205; forms.py:38-39 collocated):
+    // b += g(t) src - abs * v_stage ; every entry is a distinct dof
+    const int k0 = S.blk_bnd_off[blk], k1 = S.blk_bnd_off[blk + 1];
+    if (k1 > k0)
+    {
+      const T* vstage = stage_is_first(STAGE) ? S.v0 : S.vn;
+      for (int k = k0 + tid; k < k1; k += nthr)
+      {
+        const int gi = S.bnd_idx[k];
+        T add = S.gval * S.bnd_src[k] - S.bnd_abs[k] * vstage[gi];
+        if (NF == 2)
+          add += S.dgval * S.bnd_src2[k];
+        y_l[gi - int_off] += add;
+      }
+      __syncthreads();
+    }
     // the last dof of an odd interior range: the one-dof form of the same update
     if (tid == 0 && (sh.nint & 1))
       (void)stage_update_dof<T, STAGE>((int64_t)int_off + sh.nint - 1, (T)y_l[sh.nint - 1], S.minv, S.vn, S.un, S.u0,
                                        S.v0, S.u_, S.v_, S.adt, S.bdt, (NF == 2) ? S.m0 : nullptr,
                                        (NF == 2) ? S.mn1 : nullptr, LeanRK<T>{S.b0dt, S.r0, S.r1});
-    // degrees >= 5 (4-wave workgroups, blocks of up to 3375 dofs: four to five passes per thread): FUS_EPIU ranges per pass --
-    // at p=7 the one-range loop made the epilogue the longest phase of a block (6.9 of 19.2 us: a memory round trip per pass)
-    // (A/B at 64^3, one box: four ranges +3 % at p=7 fp64, +4 % fp32 p=6, +1.5 % fp64 p=6; six +14 % at fp32 p=7 and even at
-    // fp64; eight spills: -25 %.  profiles/r03_experiments.md section 11)
-    constexpr int EPIU = EPI2 ? 2 : ((P >= 5 && NF == 1) ? ((sizeof(T) == 4 && P == 7) ? FUS_EPIU + 2 : FUS_EPIU) : 1);
-    if constexpr (EPIU > 1)
-    {
-      for (int i = tid; i < nvec; i += EPIU * nthr)
-      {
-        Epi E[EPIU];
+    // first pass: the ranges whose HBM operands were requested before the barrier
 #pragma unroll
-        for (int u = 0; u < EPIU; ++u)
-          epi_load(i + u * nthr, E[u]);
+    for (int u = 0; u < EPIU; ++u)
+      epi_load(tid + u * nthr, Ef[u], EARLY ? 2 : 0);
 #pragma unroll
-        for (int u = 0; u < EPIU; ++u)
-          epi_store(E[u]);
-      }
-    }
-    else
+    for (int u = 0; u < EPIU; ++u)
+      epi_store(Ef[u]);
+    for (int i = tid + EPIU * nthr; i < nvec; i += EPIU * nthr)
     {
-      for (int i = tid; i < nvec; i += nthr)
-      {
-        Epi E0;
-        epi_load(i, E0);
-        epi_store(E0);
-      }
+      Epi E[EPIU];
+#pragma unroll
+      for (int u = 0; u < EPIU; ++u)
+        epi_load(i + u * nthr, E[u], 0);
+#pragma unroll
+      for (int u = 0; u < EPIU; ++u)
+        epi_store(E[u]);
     }
   }
 #pragma unroll

@@ -233,6 +233,8 @@ __host__ __device__ constexpr int epiu_of(int P, int geom, int nf)
     return (sizeof(T) == 4 && geom == GEOM_TRILINEAR) ? FUS_EPIU : 1;   // (the packed fp32 kernel: +4.5 %)
   if (sizeof(T) == 4 && P == 7)
     return geom == GEOM_TRILINEAR ? FUS_EPIU + 2 : FUS_EPIU_F32P7AFF;
+  if (sizeof(T) == 8 && P == 6 && is_aff(geom))
+    return 1;   // (four ranges: -4.5 % on the fp64 affine kernels at p=6)
   return FUS_EPIU;
 }
 // the stage update's HBM operands of the first pass requested BEFORE the barrier that ends the element trips (their

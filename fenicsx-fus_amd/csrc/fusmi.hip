@@ -1850,8 +1850,8 @@ static int op_build(fus_op* op, const uint8_t* force_shared)
                                     : (trilinear_mesh ? be_tri : (affine_mesh ? be_affine : be_stream)));
   const size_t lds_cap = two_per_cu ? 80 * 1024 : 160 * 1024;
   int waves = c->waves > 0 ? c->waves : 4;
-  if (op->P > 4 && waves > 4)
-    waves = 4;  // launch bound of the block kernel for the higher degrees
+  if (op->P > 4 && waves > FUS_MID_THREADS / 64)
+    waves = FUS_MID_THREADS / 64;  // launch bound of the block kernel for the higher degrees
   // per-cell geometry paths at p = 4 in fp64: 32 elements / 8 waves (two 8-wave blocks per CU) leave fewer
   // shared dofs than 16 / 4 -- the block kernel is 2-6 % slower, the step 1.5-3 % faster
   // (one operator input only: with two, such a block takes 92 KB of LDS and a CU holds one)

@@ -199,6 +199,10 @@ enum
 #ifndef FUS_EPIU_F32P7AFF
 #define FUS_EPIU_F32P7AFF 2
 #endif
+// threads per workgroup the kernels of the degrees 5-10 are compiled for (256; 512 = developer probe of 8-wave blocks)
+#ifndef FUS_MID_THREADS
+#define FUS_MID_THREADS 256
+#endif
 #ifndef FUS_HI_WAVES
 #define FUS_HI_WAVES 1
 #endif
@@ -2301,7 +2305,7 @@ __device__ __forceinline__ void load_stage_args(const KArgs<T, N> __attribute__(
 // derivative-table rows read from LDS where used.
 // TD = 2: the same block machinery for quadrilateral elements (Nd = N^2, GEOM_STREAM only).
 template <typename T, int P, int OP, int ATOMIC, int STAGE, int NF, int GEOM, int TD = 3, int MF = 0, int PK = 0>
-__global__ void __launch_bounds__((P <= 4) ? 512 : 256, (P >= 8) ? FUS_HI_WAVES : (P <= 4 && is_aff(GEOM))
+__global__ void __launch_bounds__((P <= 4) ? 512 : FUS_MID_THREADS, (P >= 8) ? FUS_HI_WAVES : (P <= 4 && is_aff(GEOM))
                                                             ? 4
                                                             : ((GEOM == GEOM_TRILINEAR || (is_aff(GEOM) && P <= 6)) ? FUS_TRI_WAVES_T(T, P) : (FUS_PF1(T, P, OP, ATOMIC, GEOM, TD) ? 2 : 1)))
 k_block_op(const KArgs<T, P + 1> kernel_args)

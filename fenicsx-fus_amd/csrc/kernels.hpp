@@ -200,6 +200,13 @@ enum
 #define FUS_EPIU_F32P7AFF 2
 #endif
 // threads per workgroup the kernels of the degrees 5-10 are compiled for (256; 512 = developer probe of 8-wave blocks)
+// first-batch prologue registers per thread at p = 7 (interior vectors) and at the degrees 8-10 (interior vectors, shared dofs)
+#ifndef FUS_UI_P7
+#define FUS_UI_P7 5
+#endif
+#ifndef FUS_UI_HI
+#define FUS_UI_HI 7
+#endif
 #ifndef FUS_MID_THREADS
 #define FUS_MID_THREADS 256
 #endif
@@ -2411,7 +2418,10 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   // per thread: interior 16-B vectors, shared dofs, dofmap 16-B vectors of the first batch (what a block
   // of the default size needs; larger blocks finish in the plain loops of p_commit).  Kept small: these
   // registers are live across the epilogue of the previous block when a workgroup walks several blocks.
-  constexpr int UI = (P <= 3) ? 3 : ((P == 4) ? 2 : 4), US = (P <= 3) ? 4 : ((P == 4) ? 3 : 5),
+  // (p=7: 1098 interior vectors per 8-element block and 256 threads -> five; degrees 8-10: up to 1688 interior vectors and
+  // 1538 shared dofs -> seven each: FUS_UI_HI.  With four, the remainder cost the prologue a second memory round trip.)
+  constexpr int UI = (P <= 3) ? 3 : ((P == 4) ? 2 : (P <= 6 ? 4 : (P == 7 ? FUS_UI_P7 : FUS_UI_HI))),
+                US = (P <= 3) ? 4 : ((P == 4) ? 3 : (P <= 7 ? 5 : FUS_UI_HI)),
                 UL = (P <= 3) ? 2 : ((P == 4) ? 1 : 4);
   // ---- prologue: stage the block's dof values, local dofmaps and coefficients in LDS, clear the
   // accumulator.  Every load that does not depend on another is issued first (one round trip), the

@@ -538,6 +538,7 @@ def main():
         model.init()
         info = model.data.info()
         info["mfma"] = model.data.uses_mfma()
+        info["mfma4"] = model.data.uses_mfma4()
         info["pack32"] = model.data.uses_pack32()
         info["diag_metric"] = model.data.uses_diag_metric()
         affine = model.data.geometry_mode()        # "stream" | "affine" | "trilinear"
@@ -697,7 +698,9 @@ def main():
                        "medium": args.medium,
                        "partition": "middle x-slab of 3, exchange looped back (diagnostic)" if args.halo_loopback
                        else f"x-slabs x{world}", "transport": transport if (world > 1 or args.halo_loopback) else "none",
-                       "blocks": info["nblocks"], "mfma_contractions": mfma_used, "packed_fp32": bool(info.get("pack32")),
+                       "blocks": info["nblocks"], "mfma_contractions": mfma_used,
+                       # index-1 contraction on v_mfma_f64_4x4x4_4b_f64 from the registers (p=7 fp64 trilinear kernel: default)
+                       "mfma_4x4x4_index1": bool(info.get("mfma4")), "packed_fp32": bool(info.get("pack32")),
                        "lds_bytes_per_block": info["lds_bytes"], "dt": dt,
                        **({"n1_note": "BASELINE configs[4] on ONE GPU would be 3 630 961 153 local DOFs, beyond the int32 local "
                                       "indices of the reference's dofmap (and of this library): its smallest run is N = 2; "

@@ -2312,6 +2312,11 @@ int fus_op_is_affine(fus_op* op) { return (op && op->affine) ? 1 : 0; }
 int fus_op_geometry_mode(fus_op* op) { return !op ? 0 : (op->affine ? 1 : (op->trilinear ? 2 : 0)); }
 int fus_op_uses_mfma(fus_op* op) { return (op && op->mfma) ? 1 : 0; }
 int fus_op_uses_diag_metric(fus_op* op) { return (op && op->diag) ? 1 : 0; }
+int fus_op_uses_mfma4(fus_op* op)
+{
+  // kernels.hpp mf4_contract_b: N = 8, fp64, trilinear geometry kernel, scalar (not the opt-in 16x16x4) form
+  return (op && FUS_MF4 && op->P == 7 && op->dtype == FUS_F64 && op->tdim == 3 && op->trilinear && !op->mfma) ? 1 : 0;
+}
 int fus_op_uses_pack32(fus_op* op) { return (op && op->pk && !op->mfma) ? 1 : 0; }
 
 int fus_op_info(fus_op* op, int64_t out[8])

@@ -19,7 +19,7 @@ FUS_U, FUS_V = 0, 1
 SYMBOLS = [
     "fus_last_error", "fus_version", "fus_init", "fus_finalize", "fus_synchronize", "fus_set_option",
     "fus_comm_unique_id", "fus_comm_init", "fus_comm_selftest", "fus_op_create", "fus_op_destroy", "fus_stiffness_apply",
-    "fus_mass_apply", "fus_op_get_geometry", "fus_op_get_tables", "fus_op_info", "fus_op_is_affine", "fus_op_geometry_mode", "fus_op_uses_mfma", "fus_op_uses_diag_metric", "fus_op_uses_pack32", "fus_op_hmin", "fus_op_norm2", "fus_comm_allreduce", "fus_facet_diag",
+    "fus_mass_apply", "fus_op_get_geometry", "fus_op_get_tables", "fus_op_info", "fus_op_is_affine", "fus_op_geometry_mode", "fus_op_uses_mfma", "fus_op_uses_diag_metric", "fus_op_uses_mfma4", "fus_op_uses_pack32", "fus_op_hmin", "fus_op_norm2", "fus_comm_allreduce", "fus_facet_diag",
     "fus_op_set_neighbours", "fus_model_create", "fus_model_destroy", "fus_model_set_rk_order", "fus_model_init", "fus_model_rk4",
     "fus_model_rk4_steps", "fus_model_get", "fus_model_set", "fus_model_get_mass", "fus_model_ndofs",
     "fus_profile_enable", "fus_profile_get", "fus_measure_bandwidth", "fus_layout_check", "fus_layout_check_ex", "fus_comm_init_local",

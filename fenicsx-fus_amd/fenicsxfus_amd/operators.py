@@ -125,6 +125,10 @@ class SpectralOperatorData:
     def uses_mfma(self) -> bool:
         return bool(lib().fus_op_uses_mfma(self.h))
 
+    def uses_mfma4(self) -> bool:
+        """Index-1 contraction on v_mfma_f64_4x4x4_4b_f64 (degree 7, fp64, trilinear kernel)."""
+        return bool(lib().fus_op_uses_mfma4(self.h))
+
     def uses_diag_metric(self) -> bool:
         """Affine cells with orthogonal edges: stiffness action as three 1-D stiffness contractions (fusmi.h)."""
         return bool(lib().fus_op_uses_diag_metric(self.h))

@@ -185,6 +185,10 @@ int fus_op_uses_mfma(fus_op* op);
  * the stiffness action as three 1-D stiffness contractions, sum_d g_d (M x K1 x M) x with K1 = D^T diag(w) D,
  * instead of the six derivative contractions and the pointwise transform (option "diag_metric"). */
 int fus_op_uses_diag_metric(fus_op* op);
+/* 1 when the block kernel runs its index-1 contraction on v_mfma_f64_4x4x4_4b_f64 straight from the registers (degree 7,
+ * fp64, first-order hexahedra with non-affine cells -- the trilinear geometry kernel; the default there): the reference's
+ * contract<T,8,8,8,8,bool> of spectral_op.hpp:199-201 / :222-227 (sum_factorisation.hpp:70-86) on the matrix cores. */
+int fus_op_uses_mfma4(fus_op* op);
 /* 1 when the fp32 stiffness kernel works on two elements per wave in packed float2 (degrees 5-7, per-cell
  * geometry paths, LDS-atomic accumulation; option "pack32"). */
 int fus_op_uses_pack32(fus_op* op);

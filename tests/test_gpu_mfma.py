@@ -151,3 +151,45 @@ def test_fp32_p6_two_slabs_mfma(orc):
         mdl.close()
     for cx in ctxs:
         cx.close()
+
+
+def test_mfma_4x4x4_index1_is_the_default_at_p7_fp64_trilinear(orc):
+    """v_mfma_f64_4x4x4_4b_f64 (kernels.hpp mf4_contract_b): the index-1 contraction of the p=7 fp64 trilinear kernel runs
+    on the matrix cores straight from the registers BY DEFAULT (BASELINE configs[2]'s "MFMA per-element GEMM path");
+    operator action and the fused RK4 loop against the oracle on distorted cells, mirrored cells included, and the flag
+    is off where the path is not taken (affine cells, fp32, other degrees, the opt-in 16x16x4 form)."""
+    pr = Problem(orc, (3, 3, 2), 7, hi=[0.012, 0.012, 0.008], perturb=0.2)
+    c = fa.Context(0)
+    d = fa.SpectralOperatorData(pr.V, c)
+    assert d.geometry_mode() == "trilinear" and d.uses_mfma4() and not d.uses_mfma()
+    rng = np.random.default_rng(7)
+    x, coef = rng.standard_normal(pr.ndofs), rng.uniform(0.5, 2.0, pr.mesh.num_cells)
+    y0 = rng.standard_normal(pr.ndofs)
+    y = d.stiffness(x, coef, y0.copy())
+    assert np.abs(y - (y0 + pr.K(x, coef))).max() < 1e-12 * np.abs(y).max()
+    d.close()
+    nc = pr.mesh.num_cells
+    cc, rho = np.full(nc, 1500.0), np.full(nc, 1000.0)
+    tags = fa.tag_box_boundary(pr.mesh)
+    m, src, absb, coeff = pr.linear_model_vectors(cc, rho, tags)
+    dt = 0.4 * (0.012 / 3) / (1500.0 * 49)
+    u, v = np.zeros(pr.ndofs), np.zeros(pr.ndofs)
+    orc.linear_rk4(3, pr.N, pr.dm, pr.G, pr.D, coeff, m, src, absb, 0.5e6, 6e4, 1500.0, 0.0, 6 * dt * (1 + 1e-12), dt, u, v)
+    mdl = fa.LinearSpectralExplicit(pr.mesh, tags, 7, cc, rho, 0.5e6, 6e4, 1500.0, 4, dt, V=pr.V, ctx=c)
+    assert mdl.data.uses_mfma4()
+    mdl.init()
+    mdl.rk4_steps(0.0, dt, 6)
+    assert np.abs(u).max() > 0 and np.abs(mdl.u_sol().x.array - u).max() < 1e-10 * np.abs(u).max()
+    mdl.close()
+    for P, perturb, dtype in ((7, 0.0, np.float64), (7, 0.2, np.float32), (6, 0.2, np.float64)):
+        q = Problem(orc, (2, 2, 2), P, perturb=perturb, dtype=dtype)
+        dq = fa.SpectralOperatorData(q.V, c)
+        assert not dq.uses_mfma4()
+        dq.close()
+    c.close()
+    c1 = fa.Context(0)
+    c1.set_option("mfma", 1)
+    d1 = fa.SpectralOperatorData(pr.V, c1)
+    assert d1.uses_mfma() and not d1.uses_mfma4()
+    d1.close()
+    c1.close()

@@ -252,14 +252,14 @@ def live_traffic(argv_tail, P, dtype):
 
 
 # Interior-dof vector streams of the fused stage update, in values per dof, by stage of one RK4 step
-# (kernels.hpp stage kinds 4, 5, 6, 3 = lean RK4: minv, v0 | un, vn;  minv, vn, u0, v0 | v_, un, vn;
-#  minv, vn, u0, v0, v_ | u_, v_, un, vn;  minv, vn, u_, v_ | u0, v0 -- the stage input x is counted apart;
-#  kinds 0, 1, 1, 3 with lean_rk4 = 0: 7, 10, 10, 6).  Shared dofs: the same streams plus the read of the operator input
-#  is the block kernel's gather, so k_shared_stage_planes moves one value more than the interior update (it writes b's
-#  successor vectors only): 5, 7, 10, 6 in the lean form.
-LEAN_INTERIOR = (4, 7, 9, 6)
+# (kernels.hpp stage kinds 4-7 = lean RK4 without accumulators, V_i = the stage velocities in three rotating buffers:
+#  minv, v0 | un, V_1;  minv, V_1, v0 | un, V_2;  minv, V_2, v0, V_1 | un, V_3;  minv, V_3, v0, V_1, V_2 | u0, v0 --
+#  the stage input x is counted apart and is still in LDS where the update needs it;
+#  kinds 0, 1, 1, 3 with lean_rk4 = 0: 7, 10, 10, 6).  Shared dofs: k_shared_stage_planes has no LDS copy of the stage
+#  input and reads it (u0 at stage 0, un later): one value more per stage.
+LEAN_INTERIOR = (4, 5, 6, 7)
 FULL_INTERIOR = (7, 10, 10, 6)
-LEAN_SHARED = (5, 7, 10, 6)
+LEAN_SHARED = (5, 6, 7, 8)
 
 
 def compulsory_bytes(info, nc, N3, s, geom, model="linear", lean=True):

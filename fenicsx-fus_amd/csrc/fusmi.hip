@@ -1180,7 +1180,7 @@ static int model_setup_finish(fus_model* m)
 struct StageScalars
 {
   double gval, dgval, adt, bdt;
-  double b0dt, r0, r1;  // dt b_0, b_0 / a_1, b_1 / a_2 (lean RK4 stage kinds)
+  double b0dt, pdt;    // dt b_0 and dt a_i (lean RK4 stage kinds: the stage's input is u0 + pdt V_{i-1})
   double tn;  // the stage's time t + c_i dt as the scalars above saw it (in T)
 };
 
@@ -1240,8 +1240,7 @@ static StageScalars stage_scalars(const fus_model* m, int i, double t_, double d
   sc.adt = (double)(dt * a_runge[i + 1]);
   sc.bdt = (double)(dt * b_runge[i]);
   sc.b0dt = (double)(dt * b_runge[0]);
-  sc.r0 = a_runge[1] != T(0) ? (double)(b_runge[0] / a_runge[1]) : 0.0;
-  sc.r1 = a_runge[2] != T(0) ? (double)(b_runge[1] / a_runge[2]) : 0.0;
+  sc.pdt = (double)(dt * a_runge[i]);
   sc.tn = (double)tn;
   return sc;
 }
@@ -1251,23 +1250,48 @@ static StageScalars stage_scalars(const fus_model* m, int i, double t_, double d
 // stage and swap (u_, v_) with (u0, v0) afterwards.
 static int stage_kind(const fus_model* m, int i)
 {
-  if (m->rk_order == 4 && m->lean_rk4)   // classical RK4 without the redundant accumulator streams
-    return i == 3 ? 3 : 4 + i;
+  if (m->rk_order == 4 && m->lean_rk4)   // classical RK4 without accumulator streams (kernels.hpp, stage kinds 4-7)
+    return 4 + i;
   if (i == 0)
     return 0;
   return (m->rk_order == 4 && i == 3) ? 3 : 1;
 }
 
+// The stage's velocity buffers as the fused updates name them.  Stage kinds 0, 1, 3: the model's own vn, v_, u_.
+// Lean RK4 (kinds 4-7): the three stage velocities V_1, V_2, V_3 rotate through those three buffers (A = vn, B = v_,
+// C = u_): `vn` is the velocity this stage starts from (read; stage 0 starts from v0), `v_` the one it leaves for the
+// next stage (written; at stage 3: V_2, read) and `u_` is V_1 (read at stages 2 and 3).
 template <typename T>
-static StageArgs<T> stage_args(fus_model* m, const StageScalars& sc)
+struct StageVel
+{
+  T *vn, *v_, *u_;
+};
+template <typename T>
+static StageVel<T> stage_vel(const fus_model* m, int i)
+{
+  T *A = static_cast<T*>(m->vn), *B = static_cast<T*>(m->v_), *C = static_cast<T*>(m->u_);
+  if (!(m->rk_order == 4 && m->lean_rk4))
+    return {A, B, C};
+  switch (i)
+  {
+  case 0: return {A, A, C};   // writes V_1 -> A
+  case 1: return {A, B, C};   // reads V_1, writes V_2 -> B
+  case 2: return {B, C, A};   // reads V_2 and V_1, writes V_3 -> C
+  default: return {C, B, A};  // reads V_3, V_2 and V_1
+  }
+}
+
+template <typename T>
+static StageArgs<T> stage_args(fus_model* m, int i, const StageScalars& sc)
 {
   StageArgs<T> S;
+  const StageVel<T> V = stage_vel<T>(m, i);
   S.minv = static_cast<const T*>(m->minv);
-  S.vn = static_cast<T*>(m->vn), S.un = static_cast<T*>(m->un);
+  S.vn = V.vn, S.un = static_cast<T*>(m->un);
   S.u0 = static_cast<T*>(m->u0), S.v0 = static_cast<T*>(m->v0);
-  S.u_ = static_cast<T*>(m->u_), S.v_ = static_cast<T*>(m->v_);
+  S.u_ = V.u_, S.v_ = V.v_;
   S.adt = (T)sc.adt, S.bdt = (T)sc.bdt, S.gval = (T)sc.gval;
-  S.b0dt = (T)sc.b0dt, S.r0 = (T)sc.r0, S.r1 = (T)sc.r1;
+  S.b0dt = (T)sc.b0dt, S.pdt = (T)sc.pdt, S.third = T(1) / T(3);
   S.blk_bnd_off = m->d_blk_bnd_off, S.bnd_idx = m->d_bidx;
   S.bnd_src = static_cast<const T*>(m->d_bsrc), S.bnd_abs = static_cast<const T*>(m->d_babs);
   S.x2 = nullptr, S.coef2 = static_cast<const T*>(m->coef2);
@@ -1285,8 +1309,9 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
   fus_op* op = m->op;
   const T* ustage = static_cast<const T*>(i == 0 ? m->u0 : m->un);  // a_0 = 0: un == u0
   T* b = static_cast<T*>(m->b);
-  StageArgs<T> S = stage_args<T>(m, stage_scalars<T>(m, i, t, dt));
-  S.x2 = static_cast<const T*>(i == 0 ? m->v0 : m->vn);   // lossy: second operator input v_n
+  StageArgs<T> S = stage_args<T>(m, i, stage_scalars<T>(m, i, t, dt));
+  const T* vstage = i == 0 ? static_cast<const T*>(m->v0) : S.vn;   // the velocity this stage starts from
+  S.x2 = vstage;   // lossy: second operator input v_n
   const T* G = static_cast<const T*>(op->d_G);
   const T* coef = static_cast<const T*>(m->coef);
   const int kind = stage_kind(m, i);
@@ -1299,14 +1324,14 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
     {
       switch (kind)
       {
-        FUS_STAGE_CASE(0, 2) FUS_STAGE_CASE(3, 2) FUS_STAGE_CASE(4, 2) FUS_STAGE_CASE(5, 2) FUS_STAGE_CASE(6, 2)
+        FUS_STAGE_CASE(0, 2) FUS_STAGE_CASE(3, 2) FUS_STAGE_CASE(4, 2) FUS_STAGE_CASE(5, 2) FUS_STAGE_CASE(6, 2) FUS_STAGE_CASE(7, 2)
       default:
         return launch_block_op<T, P, OP_STIFFNESS, 1, 2>(op, G, coef, ustage, b, S, b0, nb);
       }
     }
     switch (kind)
     {
-      FUS_STAGE_CASE(0, 1) FUS_STAGE_CASE(3, 1) FUS_STAGE_CASE(4, 1) FUS_STAGE_CASE(5, 1) FUS_STAGE_CASE(6, 1)
+      FUS_STAGE_CASE(0, 1) FUS_STAGE_CASE(3, 1) FUS_STAGE_CASE(4, 1) FUS_STAGE_CASE(5, 1) FUS_STAGE_CASE(6, 1) FUS_STAGE_CASE(7, 1)
     default:
       return launch_block_op<T, P, OP_STIFFNESS, 1>(op, G, coef, ustage, b, S, b0, nb);
     }
@@ -1335,8 +1360,7 @@ static int stage_begin(fus_model* m, int i, double t, double dt)
                        m->d_bidx + m->nb_int, static_cast<const T*>(m->d_bsrc) + m->nb_int,
                        static_cast<const T*>(m->d_babs) + m->nb_int, S.gval,
                        m->d_bsrc2 ? static_cast<const T*>(m->d_bsrc2) + m->nb_int : nullptr, S.dgval,
-                       static_cast<const T*>(i == 0 ? m->v0 : m->vn),
-                       static_cast<T*>(op->d_partial) + op->L.n_partial);
+                       vstage, static_cast<T*>(op->d_partial) + op->L.n_partial);
   }
   // interface dofs (held by other ranks too): this rank's partials are summed into b and into the
   // send buffer by one kernel; the event hands the buffer to the exchange
@@ -1369,9 +1393,9 @@ static int stage_end(fus_model* m, int i, double t, double dt)
   hipStream_t st = c->stream;
   const StageScalars sc = stage_scalars<T>(m, i, t, dt);
   const T adt = (T)sc.adt, bdt = (T)sc.bdt;
-  T *u0 = static_cast<T*>(m->u0), *v0 = static_cast<T*>(m->v0), *u_ = static_cast<T*>(m->u_),
-    *v_ = static_cast<T*>(m->v_), *un = static_cast<T*>(m->un), *vn = static_cast<T*>(m->vn),
-    *b = static_cast<T*>(m->b);
+  const StageVel<T> V = stage_vel<T>(m, i);
+  T *u0 = static_cast<T*>(m->u0), *v0 = static_cast<T*>(m->v0), *u_ = V.u_, *v_ = V.v_,
+    *un = static_cast<T*>(m->un), *vn = V.vn, *b = static_cast<T*>(m->b);
   const T* minv = static_cast<const T*>(m->minv);
   const T* partial = static_cast<const T*>(op->d_partial);
   const int64_t off = op->L.n_int_pad, nloc = op->L.n_shared_local;
@@ -1397,7 +1421,7 @@ static int stage_end(fus_model* m, int i, double t, double dt)
     m->bnd_valid = true, m->bnd_tn = scn.tn;
     op->bnd_owner = m;
   }
-  const LeanRK<T> R{(T)sc.b0dt, (T)sc.r0, (T)sc.r1};
+  const LeanRK<T> R{(T)sc.b0dt, (T)sc.pdt, T(1) / T(3)};
   const int kind = stage_kind(m, i);
   if (nloc > 0 && c->planes && (int)op->L.plane_cnt.size() <= (c->planes == 1 ? FUS_MAX_PLANES : c->planes))
   {
@@ -1415,7 +1439,7 @@ static int stage_end(fus_model* m, int i, double t, double dt)
     break;
     switch (kind)
     {
-      FUS_PLANES_CASE(0) FUS_PLANES_CASE(3) FUS_PLANES_CASE(4) FUS_PLANES_CASE(5) FUS_PLANES_CASE(6)
+      FUS_PLANES_CASE(0) FUS_PLANES_CASE(3) FUS_PLANES_CASE(4) FUS_PLANES_CASE(5) FUS_PLANES_CASE(6) FUS_PLANES_CASE(7)
     default:
       hipLaunchKernelGGL((k_shared_stage_planes<T, 1>), grid, blk, 0, st, nloc, PL, m->d_bnd_mask, m->d_bnd_base,
                          partial, minv + off, vn + off, un + off, u0 + off, v0 + off, u_ + off, v_ + off, adt, bdt,
@@ -1435,7 +1459,7 @@ static int stage_end(fus_model* m, int i, double t, double dt)
     break;
     switch (kind)
     {
-      FUS_SHARED_CASE(0) FUS_SHARED_CASE(3) FUS_SHARED_CASE(4) FUS_SHARED_CASE(5) FUS_SHARED_CASE(6)
+      FUS_SHARED_CASE(0) FUS_SHARED_CASE(3) FUS_SHARED_CASE(4) FUS_SHARED_CASE(5) FUS_SHARED_CASE(6) FUS_SHARED_CASE(7)
     default:
       hipLaunchKernelGGL((k_shared_stage<T, 1>), grid, blk, 0, st, nloc, m->d_sh_ptr32, m->d_sh_pairs32, partial,
                          minv + off, vn + off, un + off, u0 + off, v0 + off, u_ + off, v_ + off, adt, bdt, m0p, mn1p, B,
@@ -1462,7 +1486,7 @@ static int stage_end(fus_model* m, int i, double t, double dt)
     break;
     switch (kind)
     {
-      FUS_IF_CASE(0) FUS_IF_CASE(3) FUS_IF_CASE(4) FUS_IF_CASE(5) FUS_IF_CASE(6)
+      FUS_IF_CASE(0) FUS_IF_CASE(3) FUS_IF_CASE(4) FUS_IF_CASE(5) FUS_IF_CASE(6) FUS_IF_CASE(7)
     default:
       hipLaunchKernelGGL((k_if_unpack_stage<T, 1>), grid, blk, 0, st, op->n_uidx, op->d_uidx, op->d_uptr, op->d_usrc,
                          recv, b, minv, vn, un, u0, v0, u_, v_, adt, bdt, m0f, mn1f, op->L.n_int_pad, m->d_sh_ptr32,

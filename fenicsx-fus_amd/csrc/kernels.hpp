@@ -58,10 +58,9 @@ struct StageArgs
   const T* minv;
   T *vn, *un, *u0, *v0, *u_, *v_;
   T adt, bdt, gval;
-  // classical RK4 only (stage kinds 4-6, see stage_is_first): dt b_0, b_0 / a_1 and b_1 / a_2 of the
-  // Runge-Kutta tables, from which stages 1 and 2 rebuild the accumulators that stages 0 and 1 no longer
-  // write
-  T b0dt, r0, r1;
+  // classical RK4 only (stage kinds 4-7, see below): dt b_0, dt a_i (the factor this stage's input was built with:
+  // un = u0 + pdt * V_{i-1}) and 1 / 3
+  T b0dt, pdt, third;
   const int32_t* blk_bnd_off;
   const int32_t* bnd_idx;
   const T* bnd_src;
@@ -87,13 +86,16 @@ enum
 // Fused stage-update variants (template parameter STAGE of the block and shared-dof kernels).
 //   0 first stage, 1 middle stage, 3 last stage of RK4: every stage keeps the accumulators u_, v_ in HBM
 //     the way Linear.hpp:282-294 does (used by the Runge-Kutta orders 1-3 and option "lean_rk4" = 0);
-//   4, 5, 6 = stages 0, 1, 2 of the classical RK4 with the redundant vector streams removed: the
-//     accumulators are affine in vectors the later stages read anyway,
-//         v_ after stage 0 = v0 + (b_0 / a_1) (vn_1 - v0)               [vn_1 = v0 + a_1 dt kv_0]
-//         u_ after stage 1 = u0 + b_0 dt v0 + (b_1 / a_2) (un_2 - u0)   [un_2 = u0 + a_2 dt vn_1]
-//     so stage 0 writes neither, stage 1 writes only v_ and stage 2 rebuilds u_ -- 240 instead of 296
-//     bytes of vector traffic per dof and step, the same arithmetic up to rounding (|error| ~ eps |u|,
-//     the size of the reference's own accumulation error).
+//   4, 5, 6, 7 = stages 0-3 of the classical RK4 WITHOUT accumulators.  With V_0 = v0, U_0 = u0 and
+//         U_i = u0 + a_i dt V_{i-1},   V_i = v0 + a_i dt k_{i-1},   k_i = M^-1 (b_i - K U_i)
+//     the stage slopes are affine in the stage velocities, k_i = (V_{i+1} - v0) / (a_{i+1} dt), so
+//         u1 = u0 + dt/6 (v0 + 2 V_1 + 2 V_2 + V_3),   v1 = (V_1 + 2 V_2 + V_3 - v0) / 3 + dt/6 k_3
+//     need nothing but the three stage velocities, which live in three rotating buffers (the host passes them as
+//     vn = V_i [read], v_ = V_{i+1} [written; stage 3: V_2, read], u_ = V_1 [read, stages 2 and 3]); and u0 itself
+//     is only read at stage 0, where it IS the operator's input: later stages take it from the input already in
+//     LDS, u0 = U_i - a_i dt V_{i-1}.  Interior dofs move 4 / 5 / 6 / 7 values per stage (Linear.hpp's form: 5 / 9 / 9 / 6;
+//     round 2's lean form: 4 / 7 / 9 / 6); the same arithmetic up to rounding (|error| ~ eps |u|, the size of the
+//     reference's own accumulation error).
 __host__ __device__ constexpr bool stage_is_first(int st) { return st == 0 || st == 4; }
 
 template <typename T, int N>
@@ -2192,7 +2194,7 @@ __device__ __forceinline__ void elem_stiff_bwd(const DTab<T, N>& Dk, const T (&D
 template <typename T>
 struct LeanRK
 {
-  T b0dt, r0, r1;   // see StageArgs
+  T b0dt, pdt, third;   // see StageArgs
 };
 
 template <typename T, int STAGE>
@@ -2223,12 +2225,12 @@ __device__ __forceinline__ T stage_update_dof(int64_t s, T acc, const T* __restr
     vnext = kv * adt + v;
     FUS_ST(vn, vnext);
   }
-  else if (STAGE == 4)
+  else if (STAGE == 4)   // stage 0: the input is u0 itself
   {
     const T u = FUS_LD(u0), v = FUS_LD(v0);
     FUS_ST(un, v * adt + u);
     vnext = kv * adt + v;
-    FUS_ST(vn, vnext);
+    FUS_ST(v_, vnext);   // V_1
   }
   else if (STAGE == 3)
   {
@@ -2236,22 +2238,26 @@ __device__ __forceinline__ T stage_update_dof(int64_t s, T acc, const T* __restr
     vnext = kv * bdt + FUS_LD(v_);
     FUS_ST(v0, vnext);
   }
-  else if (STAGE == 5)
+  else if (STAGE == 5)   // stage 1: un = u0 + pdt v0, vn = V_1
   {
-    const T w = FUS_LD(vn), u = FUS_LD(u0), v = FUS_LD(v0);
-    FUS_ST(v_, kv * bdt + ((w - v) * R.r0 + v));
-    FUS_ST(un, w * adt + u);
+    const T w = FUS_LD(vn), v = FUS_LD(v0), xs = FUS_LD(un);
+    FUS_ST(un, xs + (w * adt - v * R.pdt));
     vnext = kv * adt + v;
-    FUS_ST(vn, vnext);
+    FUS_ST(v_, vnext);   // V_2
   }
-  else if (STAGE == 6)
+  else if (STAGE == 6)   // stage 2: un = u0 + pdt V_1, vn = V_2, u_ = V_1
   {
-    const T w = FUS_LD(vn), u = FUS_LD(u0), v = FUS_LD(v0), xs = FUS_LD(un);
-    FUS_ST(u_, w * bdt + ((xs - u) * R.r1 + (v * R.b0dt + u)));
-    FUS_ST(v_, kv * bdt + FUS_LD(v_));
-    FUS_ST(un, w * adt + u);
+    const T w = FUS_LD(vn), v = FUS_LD(v0), va = FUS_LD(u_), xs = FUS_LD(un);
+    FUS_ST(un, xs + (w * adt - va * R.pdt));
     vnext = kv * adt + v;
-    FUS_ST(vn, vnext);
+    FUS_ST(v_, vnext);   // V_3
+  }
+  else if (STAGE == 7)   // stage 3: un = u0 + pdt V_2, vn = V_3, u_ = V_1, v_ = V_2; the new state
+  {
+    const T w = FUS_LD(vn), v = FUS_LD(v0), va = FUS_LD(u_), vb = FUS_LD(v_), xs = FUS_LD(un);
+    FUS_ST(u0, (xs - vb * R.pdt) + ((va + vb) * T(2) + (v + w)) * R.b0dt);
+    vnext = kv * bdt + ((vb * T(2) + (va + w)) - v) * R.third;
+    FUS_ST(v0, vnext);
   }
   else
   {
@@ -2288,7 +2294,7 @@ __device__ __forceinline__ void load_stage_args(const KArgs<T, N> __attribute__(
   S.minv = q->S.minv;
   S.vn = q->S.vn, S.un = q->S.un, S.u0 = q->S.u0, S.v0 = q->S.v0, S.u_ = q->S.u_, S.v_ = q->S.v_;
   S.adt = q->S.adt, S.bdt = q->S.bdt, S.gval = q->S.gval;
-  S.b0dt = q->S.b0dt, S.r0 = q->S.r0, S.r1 = q->S.r1;
+  S.b0dt = q->S.b0dt, S.pdt = q->S.pdt, S.third = q->S.third;
   S.blk_bnd_off = q->S.blk_bnd_off, S.bnd_idx = q->S.bnd_idx;
   S.bnd_src = q->S.bnd_src, S.bnd_abs = q->S.bnd_abs;
   S.x2 = q->S.x2, S.coef2 = q->S.coef2, S.bnd_src2 = q->S.bnd_src2, S.dgval = q->S.dgval;
@@ -2900,19 +2906,19 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
       else if (STAGE == 1)
         E.au = ld(S.u_), E.av = ld(S.v_), E.a0 = ld(S.u0), E.b0 = ld(S.v0);
       else if (STAGE == 5)
-        E.a0 = ld(S.u0), E.b0 = ld(S.v0);
+        E.b0 = ld(S.v0);
       else if (STAGE == 6)
-        E.av = ld(S.v_), E.a0 = ld(S.u0), E.b0 = ld(S.v0);
+        E.b0 = ld(S.v0), E.au = ld(S.u_);
+      else if (STAGE == 7)
+        E.b0 = ld(S.v0), E.au = ld(S.u_), E.av = ld(S.v_);
       }
       if (part != 1)
       {
         constexpr bool WV2 = NF == 2;
         const A2 a2 = E.on ? reinterpret_cast<const A2*>(y_l)[E.i] : A2(0.0);
         E.bv = V2{(T)a2[0], (T)a2[1]};
-        if ((WV2 && S.mn1) || STAGE == 4 || STAGE == 6)
+        if ((WV2 && S.mn1) || STAGE >= 4)
           E.us = E.on ? reinterpret_cast<const V2*>(x_l)[E.i] : V2(T(0));   // the stage input u_n of the interior dofs is still in LDS
-        if (STAGE == 4)
-          E.a0 = E.us;
       }
     };
     auto epi_store = [&](const Epi& E) __attribute__((always_inline))
@@ -2937,8 +2943,8 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
       }
       else if (STAGE == 4)
       {
-        st(S.un, E.b0 * S.adt + E.a0);
-        st(S.vn, kv * S.adt + E.b0);
+        st(S.un, E.b0 * S.adt + E.us);
+        st(S.v_, kv * S.adt + E.b0);
       }
       else if (STAGE == 3)
       {
@@ -2947,16 +2953,18 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
       }
       else if (STAGE == 5)
       {
-        st(S.v_, kv * S.bdt + ((E.w - E.b0) * S.r0 + E.b0));
-        st(S.un, E.w * S.adt + E.a0);
-        st(S.vn, kv * S.adt + E.b0);
+        st(S.un, E.us + (E.w * S.adt - E.b0 * S.pdt));
+        st(S.v_, kv * S.adt + E.b0);
       }
       else if (STAGE == 6)
       {
-        st(S.u_, E.w * S.bdt + ((E.us - E.a0) * S.r1 + (E.b0 * S.b0dt + E.a0)));
-        st(S.v_, kv * S.bdt + E.av);
-        st(S.un, E.w * S.adt + E.a0);
-        st(S.vn, kv * S.adt + E.b0);
+        st(S.un, E.us + (E.w * S.adt - E.au * S.pdt));
+        st(S.v_, kv * S.adt + E.b0);
+      }
+      else if (STAGE == 7)
+      {
+        st(S.u0, (E.us - E.av * S.pdt) + ((E.au + E.av) * T(2) + (E.b0 + E.w)) * S.b0dt);
+        st(S.v0, kv * S.bdt + ((E.av * T(2) + (E.au + E.w)) - E.b0) * S.third);
       }
       else
       {
@@ -3034,7 +3042,7 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
     if (tid == 0 && (sh.nint & 1))
       (void)stage_update_dof<T, STAGE>((int64_t)int_off + sh.nint - 1, (T)y_l[sh.nint - 1], S.minv, S.vn, S.un, S.u0,
                                        S.v0, S.u_, S.v_, S.adt, S.bdt, (NF == 2) ? S.m0 : nullptr,
-                                       (NF == 2) ? S.mn1 : nullptr, LeanRK<T>{S.b0dt, S.r0, S.r1});
+                                       (NF == 2) ? S.mn1 : nullptr, LeanRK<T>{S.b0dt, S.pdt, S.third});
     // first pass: the ranges whose HBM operands were requested before the barrier
 #pragma unroll
     for (int u = 0; u < EPIU; ++u)

@@ -71,10 +71,11 @@ int fus_synchronize(fus_ctx* ctx);
  * "graph" (1: on one rank the launches of an RK step are captured and replayed as one hipGraph, the
  * executable graph being updated in place with each step's stage scalars; for launch-bound sizes
  * such as BASELINE config 1; default 0).
- * "lean_rk4" (set before fus_model_create; default 1): stages 0-2 of the classical RK4 do not stream the
- * accumulators u_, v_ of Linear.hpp:282-294 -- stages 1 and 2 rebuild them from vectors they read anyway
- * (240 instead of 296 bytes of vector traffic per DOF and step, same arithmetic up to rounding); 0 keeps
- * them in HBM at every stage.  The Runge-Kutta orders 1-3 always keep them.
+ * "lean_rk4" (set before fus_model_create; default 1): the classical RK4 keeps no accumulators u_, v_ of
+ * Linear.hpp:282-294 in HBM -- the stage slopes are affine in the stage velocities, so the last stage builds the
+ * new state from the three stage velocities (three rotating buffers), and u0 is rebuilt from the stage input the
+ * kernel already holds in LDS (208 instead of 296 bytes of vector traffic per DOF and step, same arithmetic up
+ * to rounding); 0 keeps them in HBM at every stage.  The Runge-Kutta orders 1-3 always keep them.
  * "mfma" (-1 auto (default) | 0 | 1, before fus_op_create): degrees 6 and 7 on the per-cell geometry
  * paths -- the index-1 / index-2 contractions of an element, the (N x N).(N x N^2) products of the
  * reference's contract<> (sum_factorisation.hpp:70-86), as 16x16x4 MFMA tiles on the matrix cores

@@ -143,8 +143,8 @@ def test_compulsory_bytes_model_and_slab_workload():
     blk, sh, det = bench.compulsory_bytes(info, nc, N3, s, "trilinear", "linear", lean=True)
     assert det["x_block_local"] == (1000 + 450) * 8 and det["gather_index_and_partial_position"] == 8 * 450
     assert det["partial_sums_written"] == 450 * 8 and det["geometry_per_cell"] == 21 * 8 * 80
-    assert det["stage_update_streams_interior"] == (4 + 7 + 9 + 6) / 4 * 8 * 1000          # lean RK4 stage kinds 4, 5, 6, 3
-    assert abs(blk - sum(det.values())) < 1e-9 and sh == (450 + (5 + 7 + 10 + 6) / 4 * 200) * 8
+    assert det["stage_update_streams_interior"] == (4 + 5 + 6 + 7) / 4 * 8 * 1000          # lean RK4 stage kinds 4, 5, 6, 7
+    assert abs(blk - sum(det.values())) < 1e-9 and sh == (450 + (5 + 6 + 7 + 8) / 4 * 200) * 8
     blk_s, _, det_s = bench.compulsory_bytes(info, nc, N3, s, "stream", "linear", lean=False)
     assert det_s["geometry_per_cell"] == 6 * N3 * 8 * 80 and det_s["stage_update_streams_interior"] == (7 + 10 + 10 + 6) / 4 * 8 * 1000
     assert blk_s > blk

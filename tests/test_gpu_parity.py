@@ -173,9 +173,9 @@ def _linear_setup(orc, ctx, n, P, hi, perturb=0.0, c0=1500.0, rho0=1000.0, heter
 
 @pytest.mark.parametrize("model_kind", ["linear", "westervelt"])
 def test_rk4_accumulator_streams_kept_or_rebuilt(orc, model_kind):
-    """Option "lean_rk4" (default 1): stages 0-2 of the classical RK4 do not keep the accumulators u_, v_
-    in HBM but rebuild them from vectors the later stages read anyway (kernels.hpp, stage kinds 4-6);
-    0 streams them at every stage like Linear.hpp:282-294.  Both against the oracle, and against each
+    """Option "lean_rk4" (default 1): the classical RK4 keeps no accumulators u_, v_ in HBM -- the last stage
+    builds the new state from the three stage velocities, and u0 is rebuilt from the stage input (kernels.hpp,
+    stage kinds 4-7); 0 streams the accumulators at every stage like Linear.hpp:282-294.  Both against the oracle, and against each
     other to rounding, on interior, shared and boundary dofs (16 blocks)."""
     L, P, n, nsteps = 0.012, 4, (6, 6, 6), 20
     pr, c, rho, tags = _linear_setup(orc, None, n, P, [L, L, L], perturb=0.1, hetero=True)

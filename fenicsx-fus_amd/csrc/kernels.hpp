@@ -209,6 +209,9 @@ enum
 #ifndef FUS_UI_HI
 #define FUS_UI_HI 7
 #endif
+#ifndef FUS_XCD_REMAP
+#define FUS_XCD_REMAP 0   // (measured: loses, see k_block_op)
+#endif
 #ifndef FUS_MID_THREADS
 #define FUS_MID_THREADS 256
 #endif
@@ -2650,7 +2653,20 @@ k_block_op(const KArgs<T, P + 1> kernel_args)
   FUS_KARGS(q0);
   const int blk_end = q0->A.blk_begin + q0->A.blk_count;
   const int blk_stride = gridDim.x;
-  int blk = blockIdx.x + q0->A.blk_begin;
+  // Developer probe (FUS_XCD_REMAP = 1; off).  Workgroups are dealt round-robin to the 8 XCDs (observed placement, a
+  // speed matter only); the remap gives workgroup i position i / 8 of the (i % 8)-th contiguous eighth of the block
+  // range, so that blocks next to each other in the layout -- which gather the same shared dofs -- run on one XCD and
+  // meet in its L2 (bijective for any grid size).  It LOSES here (p=4 fp64 -1 %, streamed G -3.6 %, fp32 +0.9 %;
+  // profiles/r03_experiments.md section 15): the kernel streams far more than it re-reads (54 % of the shared-dof
+  // gathers, 3 % of its bytes, are the only re-use), and with the default placement the eight XCDs walk the same
+  // region of every vector together instead of eight distant ones.
+  int wg = blockIdx.x;
+  if (FUS_XCD_REMAP)
+  {
+    const int G = gridDim.x, q8 = G >> 3, r8 = G & 7, xc = wg & 7;
+    wg = xc * q8 + (xc < r8 ? xc : r8) + (wg >> 3);
+  }
+  int blk = wg + q0->A.blk_begin;
   FUS_STAMP(blk, 0);
   // first trip's geometry is requested before the block's dof values are staged
   ElemIn<T, N, OP, GEOM, TD> inA, inB;

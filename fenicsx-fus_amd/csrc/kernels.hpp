@@ -271,11 +271,14 @@ __host__ __device__ constexpr int geom_cell_stride(int geom)
 // 1 / x to working precision from the hardware estimate (the per-point G of GEOM_TRILINEAR)
 __device__ __forceinline__ double fast_rcp(double x)
 {
-  // v_rcp_f64 is good to ~2^-23; one cubic step r (1 + e + e^2), e = 1 - x r, leaves e^3 ~ 2^-69 (three FMAs instead of
-  // the four of two Newton steps)
-  const double r = __builtin_amdgcn_rcp(x);
-  const double e = __builtin_fma(-x, r, 1.0);
-  return __builtin_fma(__builtin_fma(e, e, e), r, r);
+  // (two Newton steps.  One cubic step r (1 + e + e^2) -- three FMAs instead of four, enough for v_rcp_f64's ~2^-23 -- and
+  // hoisting the loop-invariant weight product out of the transform took 4 of a trip's 453 fp64 instructions and 8 VGPRs
+  // away and measured SLOWER at every degree: p=4 -0.6 %, p=5 -5.4 %, p=6 -1.7 %, p=7 -0.8 %; profiles/r03_experiments.md
+  // section 16.  The compiler's schedule of this form stays.)
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return r;
 }
 __device__ __forceinline__ float fast_rcp(float x)
 {
@@ -730,7 +733,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
       for (int a = 0; a < N; ++a)
       {
         if (GEOM == GEOM_TRILINEAR)
-          tri.transform(Dk.x[a], Dk.w[a] * (wbc * cf), F0[a], F1[a], F2[a]);
+          tri.transform(Dk.x[a], Dk.w[a] * wbc * cf, F0[a], F1[a], F2[a]);
         else
         {
           T G6[6];
@@ -838,7 +841,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
       {
         F1[a] += T(0.5) * F0[a], F2[a] -= T(0.25) * F0[a];
         if (GEOM == GEOM_TRILINEAR)
-          tri.transform(Dk.x[a], Dk.w[a] * (wbc * cf), F0[a], F1[a], F2[a]);
+          tri.transform(Dk.x[a], Dk.w[a] * wbc * cf, F0[a], F1[a], F2[a]);
         else
           F0[a] *= cf * w3[a];
       }
@@ -955,7 +958,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
         }
 #else
         if (GEOM == GEOM_TRILINEAR)
-          tri.transform(Dk.x[a], Dk.w[a] * (wbc * cf), F0[a], F1[a], F2[a]);
+          tri.transform(Dk.x[a], Dk.w[a] * wbc * cf, F0[a], F1[a], F2[a]);
 #endif
         else
         {
@@ -1089,7 +1092,7 @@ __device__ __forceinline__ void elem_compute(const ElemIn<T, N, OP, GEOM>& in, c
     {
       if (GEOM == GEOM_TRILINEAR)
       {
-        tri.transform(Dk.x[a], Dk.w[a] * (wbc * cf), F0[a], F1[a], F2[a]);
+        tri.transform(Dk.x[a], Dk.w[a] * wbc * cf, F0[a], F1[a], F2[a]);
         continue;
       }
       T G6[6];
@@ -1964,7 +1967,7 @@ __device__ __forceinline__ void elem_compute_mfma(const ElemIn<T, N, OP_STIFFNES
     for (int a = 0; a < N; ++a)
     {
       if (GEOM == GEOM_TRILINEAR)
-        tri.transform(Dk.x[a], Dk.w[a] * (wbc * cf), F0[a], F1[a], F2[a]);
+        tri.transform(Dk.x[a], Dk.w[a] * wbc * cf, F0[a], F1[a], F2[a]);
       else
       {
         T G6[6];

@@ -702,6 +702,12 @@ def main():
                        # index-1 contraction on v_mfma_f64_4x4x4_4b_f64 from the registers (p=7 fp64 trilinear kernel: default)
                        "mfma_4x4x4_index1": bool(info.get("mfma4")), "packed_fp32": bool(info.get("pack32")),
                        "lds_bytes_per_block": info["lds_bytes"], "dt": dt,
+                       # the RK4 stage update: fused into the kernels' epilogues; values per interior dof and step
+                       "rk4_update": ("fused, classical RK4 without accumulator vectors (kernels.hpp stage kinds 4-7): "
+                                      f"{sum(LEAN_INTERIOR)} values per interior dof and step"
+                                      if (args.lean_rk4 is None or args.lean_rk4 == 1) else
+                                      f"fused, accumulators streamed as in Linear.hpp:282-294: {sum(FULL_INTERIOR)} values per "
+                                      "interior dof and step"),
                        **({"n1_note": "BASELINE configs[4] on ONE GPU would be 3 630 961 153 local DOFs, beyond the int32 local "
                                       "indices of the reference's dofmap (and of this library): its smallest run is N = 2; "
                                       "per-GPU-size lines use --cells-xyz 32 256 256"}

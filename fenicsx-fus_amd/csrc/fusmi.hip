@@ -135,6 +135,7 @@ struct Prof
   std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
   double done_ms = 0;
   int64_t done_count = 0;
+  int64_t seen = 0;   // scopes of this name since fus_profile_enable (level 2 samples every prof_sample-th)
 };
 
 struct fus_ctx
@@ -153,6 +154,7 @@ struct fus_ctx
   // on MI355X at p=4 fp64, profiles/r01_block_sweep.txt)
   int block_elems = 0, waves = 0;
   int prof = 0;  // 0 off, 1 all scopes, 2 block-operator kernel only
+  int prof_sample = 1;  // level 2: events around every prof_sample-th launch of the block-operator kernel (option "profile_sample")
   std::map<std::string, Prof> profs;
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1;
@@ -323,7 +325,10 @@ struct ProfScope
   {
     // level 1: every scope; level 2: the dominant kernel only ("stiffness", "stiffness_if") -- each
     // event record drains the queue between two kernels, so a timed run keeps them to a minimum
-    if (c->prof == 1 || (c->prof == 2 && !strncmp(name, "stiffness", 9)))
+    bool take = c->prof == 1;
+    if (c->prof == 2 && !strncmp(name, "stiffness", 9))
+      take = (c->profs[name].seen++ % c->prof_sample) == 0;
+    if (take)
     {
       p = &c->profs[name];
       (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
@@ -2013,6 +2018,12 @@ int fus_set_option(fus_ctx* c, const char* key, int64_t value)
     if (value < -1 || value > 1)
       return fail(FUS_ERR_ARG, "pack32 must be -1 (auto), 0 or 1");
     c->pack32 = (int)value;
+  }
+  else if (!strcmp(key, "profile_sample"))
+  {
+    if (value < 1 || value > 1000)
+      return fail(FUS_ERR_ARG, "profile_sample must be 1..1000");
+    c->prof_sample = (int)value;
   }
   else if (!strcmp(key, "planes"))
   {
